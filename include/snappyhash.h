@@ -1,0 +1,160 @@
+/*
+ * libsnappyhash -- C ABI of the MI355X (gfx950) asset hot path.
+ *
+ * Every entry point replaces one managed call of the reference plugin (paths
+ * are relative to /root/reference).  The reference has no native interface for
+ * this path: the seam is the static method `string Crypto.GetHash(byte[])`
+ * (Snappy/Utils/Crypto.cs:8) with its three call sites, and the idiom
+ * `new LZ4Stream(fs, Decompress, ...).CopyTo(ms)` (Snappy/Features/Mcdf/
+ * McdfManager.cs:73-79).  The shapes below are what a P/Invoke shim for those
+ * call sites binds.
+ *
+ * Conventions
+ *   - Plain pointers and sizes only.  The caller owns every buffer; the library
+ *     keeps no pointer after a call returns and hands out no memory.
+ *   - Every call is synchronous and blocking, like the managed originals, and
+ *     safe to call from several threads at once (the reference hashes from the
+ *     UI thread and from a thread-pool task: Snappy/Plugin.cs:257-278).
+ *   - Return value: SNAPPY_OK (0) or a negative SNAPPY_E_* code.  Nothing throws
+ *     or aborts across the ABI.  There is no CPU fallback: without a usable
+ *     gfx950 device every compute entry point returns SNAPPY_E_NO_DEVICE.
+ *   - "host" pointers are ordinary process memory.  "device" pointers are HIP
+ *     device allocations on the device named by the call.
+ */
+#ifndef SNAPPYHASH_H
+#define SNAPPYHASH_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ status */
+#define SNAPPY_OK                  0
+#define SNAPPY_E_INVALID_ARG     (-1)  /* null pointer, bad device index, range overflow          */
+#define SNAPPY_E_NO_DEVICE       (-2)  /* no gfx950 device / HIP runtime unusable                 */
+#define SNAPPY_E_HIP             (-3)  /* a HIP call failed; see snappy_last_error_detail()       */
+#define SNAPPY_E_NOMEM           (-4)  /* host or device allocation failed                        */
+/* lz4net LZ4Stream read errors (the managed reader throws in each of these cases) */
+#define SNAPPY_E_LZ4_TRUNCATED   (-10) /* EOF inside a varint or a chunk payload (EndOfStream)    */
+#define SNAPPY_E_LZ4_BAD_LENGTHS (-11) /* compressedLength > originalLength, or negative as int   */
+#define SNAPPY_E_LZ4_PASSES      (-12) /* chunk flags ask for multi-pass decode (NotSupported)    */
+#define SNAPPY_E_LZ4_CORRUPT     (-13) /* block does not decode to exactly originalLength bytes   */
+#define SNAPPY_E_CAPACITY        (-14) /* caller's output buffer is too small                     */
+/* McdfHeader.ReadHeader / FromBinaryReader errors (Snappy/Features/Mcdf/McdfHeader.cs:26-62) */
+#define SNAPPY_E_MCDF_MAGIC      (-20) /* first four bytes are not "MCDF"                         */
+#define SNAPPY_E_MCDF_VERSION    (-21) /* version byte != 1                                       */
+#define SNAPPY_E_MCDF_TRUNCATED  (-22) /* payload ends inside the header                          */
+#define SNAPPY_E_MCDF_JSON       (-23) /* header JSON does not parse into McdfData                */
+
+/* Per-file status written by the MCDF entry points (McdfManager.cs:36-63). */
+#define SNAPPY_FILE_HASHED             0
+#define SNAPPY_FILE_SKIPPED_EMPTY      1 /* Length == 0: `continue` at McdfManager.cs:39-40       */
+#define SNAPPY_FILE_SKIPPED_SHORT_READ 2 /* ReadBytes came up short: logged + skipped, :43-49     */
+
+/* --------------------------------------------------------------- lifecycle */
+
+/* Binds the first n_devices visible gfx950 devices (n_devices <= 0: all).
+ * Optional: every entry point initialises on first use with all devices.
+ * Replaces nothing in the reference (managed code needs no set-up). */
+int snappy_init(int n_devices);
+/* Releases streams, staging buffers and device arenas.  Not safe while other
+ * calls are in flight. */
+void snappy_shutdown(void);
+/* Number of devices the library is using (0 before a successful init). */
+int snappy_device_count(void);
+/* Static, NUL-terminated description of a status code. */
+const char *snappy_strerror(int code);
+/* Thread-local detail of the last SNAPPY_E_HIP on this thread ("" if none). */
+const char *snappy_last_error_detail(void);
+
+/* ------------------------------------------------------------------- SHA-1 */
+
+/* Crypto.GetHash without the formatting (Snappy/Utils/Crypto.cs:10-11,
+ * SHA1.Create().ComputeHash(bytes)): 20-byte SHA-1 of data[0..len).
+ * data may be NULL when len == 0. */
+int snappy_sha1(const uint8_t *data, uint64_t len, uint8_t out20[20]);
+
+/* Exactly Crypto.GetHash (Snappy/Utils/Crypto.cs:8-22): 40 UPPERCASE hex
+ * characters followed by NUL. */
+int snappy_sha1_hex(const uint8_t *data, uint64_t len, char out41[41]);
+
+/* The three hash loops collapsed (Snappy/Core/SnapshotManager.cs:312-324,
+ * Snappy/Features/Mcdf/McdfManager.cs:36-63, Snappy/Data/SnapshotMigrator.cs:
+ * 62-86): digests[20*i .. 20*i+20) = SHA-1(base + offsets[i], lengths[i]).
+ * All pointers are host memory.  lengths[i] == 0 is allowed (digest of the
+ * empty message); the MCDF loop's skip of empty entries is the caller's. */
+int snappy_sha1_batch(const uint8_t *base, const uint64_t *offsets,
+                      const uint64_t *lengths, uint64_t n, uint8_t *digests);
+
+/* Same loop for files read into separate arrays (File.ReadAllBytes per file,
+ * SnapshotManager.cs:317): digests[20*i..] = SHA-1(datas[i], lengths[i]). */
+int snappy_sha1_files(const uint8_t *const *datas, const uint64_t *lengths,
+                      uint64_t n, uint8_t *digests);
+
+/* Crypto.ToHashedString for n digests (Snappy/Utils/Crypto.cs:14-22):
+ * hex[41*i..] = 40 uppercase hex chars + NUL.  Pure host formatting. */
+int snappy_digests_to_hex(const uint8_t *digests, uint64_t n, char *hex);
+
+/* snappy_sha1_batch over data that already lives in HBM on `device`
+ * (0 <= device < snappy_device_count()).  d_base is a device pointer; offsets,
+ * lengths and digests are host memory.  `stream` is a hipStream_t on that
+ * device or NULL for a library stream; the call returns after the digests
+ * have landed.  No counterpart in the reference (it hashes managed arrays);
+ * it is the loop above for callers that keep assets resident on the GPU. */
+int snappy_sha1_batch_device(int device, const void *d_base, const uint64_t *offsets,
+                             const uint64_t *lengths, uint64_t n, uint8_t *digests,
+                             void *stream);
+
+/* ----------------------------------------------------- lz4net stream + MCDF */
+
+/* Walks the chunk headers of an lz4net LZ4Stream (what McdfManager.cs:73-79
+ * reads) and returns the decoded size: the length the MemoryStream would have
+ * after CopyTo.  Host only.  Reports the structural errors
+ * (TRUNCATED / BAD_LENGTHS / PASSES), not block corruption. */
+int snappy_lz4net_decoded_size(const uint8_t *in, uint64_t in_len, uint64_t *out_len);
+
+/* `lz4Stream.CopyTo(memoryStream)` (McdfManager.cs:72-80): decodes every chunk
+ * of the stream into out[0..*out_len).  Host pointers; the LZ4 blocks are
+ * decoded on the GPU. */
+int snappy_lz4net_decode(const uint8_t *in, uint64_t in_len, uint8_t *out,
+                         uint64_t out_cap, uint64_t *out_len);
+
+/* McdfHeader.FromBinaryReader (Snappy/Features/Mcdf/McdfHeader.cs:26-62) on a
+ * decoded payload: checks "MCDF" + version 1, parses the JSON (McdfData.cs:
+ * 9-13,25) and reports the file table.  Host only.
+ *   *n_files      number of entries of Files
+ *   *body_offset  offset of the first file body in the payload
+ * file_lengths may be NULL to query *n_files; otherwise it receives up to
+ * lengths_cap entries (SNAPPY_E_CAPACITY when too small). */
+int snappy_mcdf_parse_header(const uint8_t *payload, uint64_t payload_len,
+                             uint64_t *n_files, uint64_t *body_offset,
+                             int64_t *file_lengths, uint64_t lengths_cap);
+
+/* ImportMcdf data path, fused (McdfManager.cs:72-80 decode + :28-66 slice and
+ * hash): decodes the lz4net stream on the GPU, parses the header on the host,
+ * and hashes every file body where it lies in HBM.
+ *   digests      n_files*20 bytes; entries whose status is not HASHED are zero
+ *   statuses     n_files bytes of SNAPPY_FILE_*
+ *   out_payload  NULL, or room for the decoded payload (out_cap bytes)
+ * n_files_cap is the capacity of digests/statuses in entries. */
+int snappy_mcdf_decode_and_hash(const uint8_t *in, uint64_t in_len,
+                                uint8_t *digests, uint8_t *statuses, uint64_t n_files_cap,
+                                uint64_t *n_files, uint64_t *body_offset,
+                                uint8_t *out_payload, uint64_t out_cap, uint64_t *payload_len);
+
+/* --------------------------------------------------------------- profiling */
+
+/* Kernel timing of the most recent compute call made by this thread, measured
+ * with HIP events recorded on the stream the kernels ran on.  kernel: 0 = SHA-1
+ * kernels, 1 = LZ4 decode kernel.  Returns milliseconds, or a negative value
+ * when that kernel did not run.  snappy_profile_enable(1) turns recording on
+ * (off by default).  No counterpart in the reference. */
+void snappy_profile_enable(int on);
+float snappy_profile_last_ms(int kernel);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SNAPPYHASH_H */

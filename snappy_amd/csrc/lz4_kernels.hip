@@ -1,0 +1,333 @@
+// Wave-cooperative LZ4 block decoder for gfx950.
+//
+// Decodes the chunks of an lz4net LZ4Stream -- what
+// /root/reference/Snappy/Features/Mcdf/McdfManager.cs:73-79 obtains from
+// `new LZ4Stream(fs, Decompress, ...).CopyTo(ms)`.  Chunks are independent raw
+// LZ4 blocks (or stored bytes), so one wavefront owns one chunk at a time and
+// draws chunks from a device queue.
+//
+// Inside a chunk the token stream is serial.  The wave keeps a 256-byte window
+// of the compressed input spread over its 64 lanes (one dword per lane) and
+// parses tokens on the scalar unit with v_readlane, so parsing never waits on
+// memory except to slide the window.  Literal and match copies are done by all
+// 64 lanes with consecutive lanes on consecutive bytes.  A match whose offset
+// is smaller than its length repeats a pattern of `offset` bytes; it is copied
+// as out[op+i] = out[op-offset + i mod offset], which reads only bytes written
+// by earlier sequences, so every lane can go at once.
+//
+// Acceptance rules are those of the decoder lz4net ports (LZ4 r7x
+// LZ4_uncompress with a known output length): a literal run that ends within 8
+// bytes of the end must end the block exactly; a match must end at least 5
+// bytes before the end; consumed input must equal the chunk's compressed
+// length.  Every read and write is bounds-checked against the chunk, so a
+// corrupt stream yields a status word, never a stray access.
+#include "lz4_launch.hpp"
+
+namespace snappy {
+
+namespace {
+
+constexpr int kWave = 64;
+constexpr uint32_t kCopyLength = 8;
+constexpr uint32_t kLastLiterals = 5;
+
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// 256-byte window of the chunk's compressed bytes: lane l holds the aligned
+// dword number (first_dword + l) counted from `aligned`.
+struct InputWindow {
+    const uint32_t *aligned;  // dword-aligned pointer at or below the chunk's first byte
+    uint32_t limit_dwords;    // dwords that may be read from `aligned`
+    uint32_t first_dword;     // uniform
+    uint32_t dword;           // per lane
+
+    __device__ __forceinline__ void fill(uint32_t first, uint32_t lane)
+    {
+        first_dword = first;
+        const uint32_t idx = first + lane;
+        dword = (idx < limit_dwords) ? aligned[idx] : 0u;
+    }
+
+    // The four bytes at byte position `pos` (counted from `aligned`), little-endian.
+    __device__ __forceinline__ uint32_t peek32(uint32_t pos, uint32_t lane)
+    {
+        uint32_t di = (pos >> 2) - first_dword;
+        if (di >= 63u) {  // also catches positions before the window
+            fill(pos >> 2, lane);
+            di = 0;
+        }
+        const uint32_t lo = __builtin_amdgcn_readlane(dword, di);
+        const uint32_t hi = __builtin_amdgcn_readlane(dword, di + 1u);
+        const uint64_t both = (static_cast<uint64_t>(hi) << 32) | lo;
+        return static_cast<uint32_t>(both >> ((pos & 3u) * 8u));
+    }
+};
+
+// Lanes copy n bytes, consecutive lanes on consecutive bytes.  src and dst do
+// not overlap within the copy.
+__device__ __forceinline__ void copy_bytes(uint8_t *dst, const uint8_t *src, uint32_t n,
+                                           uint32_t lane)
+{
+    uint32_t i = lane;
+    // Four loads in flight per lane before the first store.
+    for (; i + 3u * kWave < n; i += 4u * kWave) {
+        const uint8_t a = src[i], b = src[i + kWave], c = src[i + 2 * kWave], d = src[i + 3 * kWave];
+        dst[i] = a;
+        dst[i + kWave] = b;
+        dst[i + 2 * kWave] = c;
+        dst[i + 3 * kWave] = d;
+    }
+    for (; i < n; i += kWave)
+        dst[i] = src[i];
+}
+
+// Same for long runs, one dword per lane: the destination is brought to a dword
+// boundary, source dwords are read aligned and funnel-shifted (v_alignbyte_b32)
+// by the source's misalignment.
+__device__ __forceinline__ void copy_long(uint8_t *dst, const uint8_t *src, uint32_t n,
+                                          uint32_t lane)
+{
+    // Bring dst to a dword boundary.
+    const uint32_t head = (4u - static_cast<uint32_t>(reinterpret_cast<uintptr_t>(dst) & 3u)) & 3u;
+    if (head) {
+        if (lane < head)
+            dst[lane] = src[lane];
+        dst += head;
+        src += head;
+        n -= head;
+    }
+    const uint32_t shift = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(src) & 3u);
+    const uint32_t *s = reinterpret_cast<const uint32_t *>(src - shift);
+    uint32_t *d = reinterpret_cast<uint32_t *>(dst);
+    const uint32_t n_dwords = n >> 2;
+    // dst dword k = bytes [4k+shift, 4k+shift+4) of s: funnel of s[k] and s[k+1].
+    // s[k+1] is read only when it holds source bytes (shift != 0).
+    uint32_t k = lane;
+    for (; k + kWave < n_dwords; k += 2u * kWave) {
+        const uint32_t a0 = s[k], b0 = s[k + kWave];
+        const uint32_t a1 = shift ? s[k + 1] : 0u, b1 = shift ? s[k + kWave + 1] : 0u;
+        d[k] = __builtin_amdgcn_alignbyte(a1, a0, shift);
+        d[k + kWave] = __builtin_amdgcn_alignbyte(b1, b0, shift);
+    }
+    for (; k < n_dwords; k += kWave) {
+        const uint32_t a0 = s[k];
+        const uint32_t a1 = shift ? s[k + 1] : 0u;
+        d[k] = __builtin_amdgcn_alignbyte(a1, a0, shift);
+    }
+    const uint32_t done = n_dwords << 2;
+    if (lane < (n & 3u))
+        dst[done + lane] = src[done + lane];
+}
+
+constexpr uint32_t kLongCopy = 512;
+
+__device__ __forceinline__ void copy_run(uint8_t *dst, const uint8_t *src, uint32_t n,
+                                         uint32_t lane)
+{
+    if (n >= kLongCopy)
+        copy_long(dst, src, n, lane);
+    else
+        copy_bytes(dst, src, n, lane);
+}
+
+// Overlapping match: the output repeats the `period` bytes that end at dst.
+// The first `span` bytes (a multiple of the period, at least kPeriodSpan) are
+// written as dst[i] = dst[i mod period - period], which reads only bytes that
+// existed before the match; the rest repeats with distance `span`, a plain
+// forward copy in pieces of `span` bytes, each piece reading the one before.
+constexpr uint32_t kPeriodSpan = 4096;
+
+__device__ __forceinline__ void copy_periodic(uint8_t *dst, uint32_t period, uint32_t n,
+                                              uint32_t lane)
+{
+    const uint8_t *pat = dst - period;
+    const uint32_t reps = (kPeriodSpan + period - 1u) / period;
+    const uint32_t span = reps * period;
+    const uint32_t head = n < span ? n : span;
+    if (period >= 4u * kWave) {
+        // Long pattern: each repetition is a plain copy of the pattern itself.
+        for (uint32_t at = 0; at < head; at += period)
+            copy_run(dst + at, pat, (head - at < period) ? head - at : period, lane);
+    } else {
+        uint32_t r = lane % period;
+        const uint32_t step = kWave % period;
+        uint32_t i = lane;
+        for (; i + 3u * kWave < head; i += 4u * kWave) {
+            uint32_t r1 = r + step;
+            r1 -= (r1 >= period) ? period : 0u;
+            uint32_t r2 = r1 + step;
+            r2 -= (r2 >= period) ? period : 0u;
+            uint32_t r3 = r2 + step;
+            r3 -= (r3 >= period) ? period : 0u;
+            const uint8_t a = pat[r], b = pat[r1], c = pat[r2], d = pat[r3];
+            dst[i] = a;
+            dst[i + kWave] = b;
+            dst[i + 2 * kWave] = c;
+            dst[i + 3 * kWave] = d;
+            r = r3 + step;
+            r -= (r >= period) ? period : 0u;
+        }
+        for (; i < head; i += kWave) {
+            dst[i] = pat[r];
+            r += step;
+            r -= (r >= period) ? period : 0u;
+        }
+    }
+    for (uint32_t done = head; done < n; done += span) {
+        const uint32_t piece = (n - done < span) ? n - done : span;
+        copy_run(dst + done, dst + done - span, piece, lane);
+    }
+}
+
+// Decodes one compressed chunk; returns true when the block is well-formed.
+__device__ bool decode_block(const uint8_t *__restrict__ in_base, uint64_t in_alloc,
+                             const Lz4Chunk &ck, uint8_t *out_base, uint32_t lane)
+{
+    const uint8_t *src = in_base + ck.in_off;
+    uint8_t *dst = out_base + ck.out_off;
+    const uint32_t in_shift = static_cast<uint32_t>(ck.in_off & 3u);
+    const uint32_t iend = ck.comp_len + in_shift;  // positions are counted from the aligned base
+    const uint32_t oend = ck.orig_len;
+
+    InputWindow win;
+    win.aligned = reinterpret_cast<const uint32_t *>(src - in_shift);
+    const uint64_t avail = in_alloc - (ck.in_off - in_shift);
+    win.limit_dwords = static_cast<uint32_t>(avail >> 2 > 0xFFFFFFFFull ? 0xFFFFFFFFull : avail >> 2);
+    win.fill(0, lane);
+
+    uint32_t ip = in_shift;  // uniform
+    uint32_t op = 0;         // uniform
+    const uint8_t *src_al = src - in_shift;
+
+    for (;;) {
+        if (ip >= iend)
+            return false;
+        uint32_t bytes = uni(win.peek32(ip, lane));
+        const uint32_t token = bytes & 0xFFu;
+        ip += 1;
+
+        // Literal length.
+        uint32_t lit = token >> 4;
+        if (lit == 15u) {
+            for (;;) {
+                if (ip + 4u <= iend) {
+                    bytes = uni(win.peek32(ip, lane));
+                    if (bytes == 0xFFFFFFFFu) {
+                        lit += 4u * 255u;
+                        ip += 4;
+                        if (lit > oend)
+                            return false;
+                        continue;
+                    }
+                } else if (ip >= iend) {
+                    return false;
+                } else {
+                    bytes = uni(win.peek32(ip, lane));
+                }
+                const uint32_t b = bytes & 0xFFu;
+                lit += b;
+                ip += 1;
+                if (b != 255u)
+                    break;
+            }
+        }
+        if (lit > oend - op || lit > iend - ip)
+            return false;
+        const bool last = (op + lit + kCopyLength > oend);
+        if (last && op + lit != oend)
+            return false;
+        if (lit)
+            copy_run(dst + op, src_al + ip, lit, lane);
+        ip += lit;
+        op += lit;
+        if (last)
+            return ip == iend;
+
+        // Match offset.
+        if (ip + 2u > iend)
+            return false;
+        bytes = uni(win.peek32(ip, lane));
+        const uint32_t offset = bytes & 0xFFFFu;
+        ip += 2;
+        if (offset == 0u || offset > op)
+            return false;
+
+        // Match length.
+        uint32_t ml = token & 15u;
+        if (ml == 15u) {
+            for (;;) {
+                if (ip + 4u <= iend) {
+                    bytes = uni(win.peek32(ip, lane));
+                    if (bytes == 0xFFFFFFFFu) {
+                        ml += 4u * 255u;
+                        ip += 4;
+                        if (ml > oend)
+                            return false;
+                        continue;
+                    }
+                } else if (ip >= iend) {
+                    return false;
+                } else {
+                    bytes = uni(win.peek32(ip, lane));
+                }
+                const uint32_t b = bytes & 0xFFu;
+                ml += b;
+                ip += 1;
+                if (b != 255u)
+                    break;
+            }
+        }
+        ml += 4u;
+        if (ml > oend - op || op + ml + kLastLiterals > oend)
+            return false;
+
+        uint8_t *mdst = dst + op;
+        const uint8_t *msrc = mdst - offset;
+        if (offset >= ml) {
+            copy_run(mdst, msrc, ml, lane);
+        } else {
+            copy_periodic(mdst, offset, ml, lane);
+        }
+        op += ml;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+lz4_decode_kernel(const uint8_t *__restrict__ in_base, uint64_t in_alloc, uint8_t *out_base,
+                  const Lz4Chunk *__restrict__ chunks, uint32_t n_chunks,
+                  uint32_t *__restrict__ queue, uint32_t *__restrict__ status)
+{
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    for (;;) {
+        uint32_t i = 0;
+        if (lane == 0)
+            i = atomicAdd(queue, 1u);
+        i = uni(i);
+        if (i >= n_chunks)
+            break;
+        const Lz4Chunk ck = chunks[i];
+        bool ok = true;
+        if (ck.compressed) {
+            ok = decode_block(in_base, in_alloc, ck, out_base, lane);
+        } else {
+            copy_run(out_base + ck.out_off, in_base + ck.in_off, ck.orig_len, lane);
+        }
+        if (lane == 0)
+            status[i] = ok ? 0u : 1u;
+    }
+}
+
+}  // namespace
+
+hipError_t launch_lz4_decode(const uint8_t *d_in, uint64_t in_alloc, uint8_t *d_out,
+                             const Lz4Chunk *d_chunks, uint32_t n_chunks, uint32_t *d_queue,
+                             uint32_t *d_status, int blocks, hipStream_t stream)
+{
+    if (n_chunks == 0 || blocks <= 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(lz4_decode_kernel, dim3(blocks), dim3(256), 0, stream, d_in, in_alloc, d_out,
+                       d_chunks, n_chunks, d_queue, d_status);
+    return hipGetLastError();
+}
+
+}  // namespace snappy

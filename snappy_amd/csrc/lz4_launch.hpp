@@ -1,0 +1,27 @@
+// Host-side launch interface of the LZ4 decode kernel (lz4_kernels.hip).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace snappy {
+
+// One chunk of an lz4net LZ4Stream, located in the device copies of the
+// compressed stream (in_off) and of the decoded payload (out_off).
+struct Lz4Chunk {
+    uint64_t in_off;
+    uint64_t out_off;
+    uint32_t comp_len;    // payload bytes in the stream
+    uint32_t orig_len;    // decoded bytes
+    uint32_t compressed;  // 0 = stored
+    uint32_t reserved;
+};
+
+// Decodes n_chunks chunks.  d_in holds the stream and at least in_alloc
+// readable bytes (in_alloc a multiple of 4, covering the stream plus slack);
+// *d_queue must be zero at launch; d_status[i] receives 0 (ok) or 1 (corrupt).
+hipError_t launch_lz4_decode(const uint8_t *d_in, uint64_t in_alloc, uint8_t *d_out,
+                             const Lz4Chunk *d_chunks, uint32_t n_chunks, uint32_t *d_queue,
+                             uint32_t *d_status, int blocks, hipStream_t stream);
+
+}  // namespace snappy

@@ -1,0 +1,213 @@
+// lz4net LZ4Stream read side: chunk-header walk on the host, block decode on
+// the GPU.  Replaces `new LZ4Stream(fs, LZ4StreamMode.Decompress, ...)
+// .CopyTo(memoryStream)` of /root/reference/Snappy/Features/Mcdf/McdfManager.cs:
+// 72-80.  lz4net (NuGet 1.0.15.93, Snappy/Snappy.csproj:56) is not in the
+// reference tree; the framing below follows its LZ4Stream.AcquireNextChunk:
+//
+//   chunk   := varint(flags) varint(originalLength)
+//              [varint(compressedLength) if flags & 1] payload
+//   flags   : bit0 compressed, bit1 high-compression (ignored when reading),
+//             bits 2.. passes (must be 0 for a compressed chunk)
+//   varint  : little-endian base-128, at most 64 bits
+//   payload : one raw LZ4 block of compressedLength bytes, or originalLength
+//             stored bytes
+//   end     : EOF exactly at a chunk boundary
+#include "lz4net_host.hpp"
+
+#include <algorithm>
+#include <cstring>
+
+namespace snappy {
+
+namespace {
+
+// 1 = value read, 0 = EOF before the first byte, -1 = EOF inside the varint.
+int read_varint(const uint8_t *in, uint64_t in_len, uint64_t &pos, uint64_t &value)
+{
+    uint64_t result = 0;
+    unsigned count = 0;
+    for (;;) {
+        if (pos >= in_len)
+            return count == 0 ? 0 : -1;
+        const unsigned b = in[pos++];
+        result += static_cast<uint64_t>(b & 0x7F) << count;
+        count += 7;
+        if ((b & 0x80) == 0 || count >= 64)
+            break;
+    }
+    value = result;
+    return 1;
+}
+
+}  // namespace
+
+void parse_lz4net_stream(const uint8_t *in, uint64_t in_len, Lz4netLayout &layout)
+{
+    layout.chunks.clear();
+    layout.decoded_size = 0;
+    layout.stop_status = SNAPPY_OK;
+    uint64_t pos = 0;
+    for (;;) {
+        uint64_t v = 0;
+        int r = read_varint(in, in_len, pos, v);
+        if (r == 0)
+            return;  // clean end of stream
+        if (r < 0) {
+            layout.stop_status = SNAPPY_E_LZ4_TRUNCATED;
+            return;
+        }
+        // The managed reader narrows all three fields to 32-bit ints.
+        const int32_t flags = static_cast<int32_t>(static_cast<uint32_t>(v));
+        const bool compressed = (flags & 1) != 0;
+        if (read_varint(in, in_len, pos, v) != 1) {
+            layout.stop_status = SNAPPY_E_LZ4_TRUNCATED;
+            return;
+        }
+        const int32_t original = static_cast<int32_t>(static_cast<uint32_t>(v));
+        int32_t comp = original;
+        if (compressed) {
+            if (read_varint(in, in_len, pos, v) != 1) {
+                layout.stop_status = SNAPPY_E_LZ4_TRUNCATED;
+                return;
+            }
+            comp = static_cast<int32_t>(static_cast<uint32_t>(v));
+        }
+        if (original < 0 || comp < 0 || comp > original) {
+            layout.stop_status = SNAPPY_E_LZ4_BAD_LENGTHS;
+            return;
+        }
+        if (pos + static_cast<uint64_t>(comp) > in_len) {
+            layout.stop_status = SNAPPY_E_LZ4_TRUNCATED;
+            return;
+        }
+        if (compressed && (flags >> 2) != 0) {
+            layout.stop_status = SNAPPY_E_LZ4_PASSES;
+            return;
+        }
+        Lz4Chunk c{};
+        c.in_off = pos;
+        c.out_off = layout.decoded_size;
+        c.comp_len = static_cast<uint32_t>(comp);
+        c.orig_len = static_cast<uint32_t>(original);
+        c.compressed = compressed ? 1u : 0u;
+        pos += static_cast<uint64_t>(comp);
+        layout.decoded_size += static_cast<uint64_t>(original);
+        if (original != 0)  // empty chunks are skipped by the reader
+            layout.chunks.push_back(c);
+    }
+}
+
+int decode_lz4net_on_device(SlotLease &lease, const uint8_t *in, uint64_t in_len,
+                            const Lz4netLayout &layout, DecodedOnDevice &out)
+{
+    Slot &s = *lease.slot;
+    const uint64_t n_chunks = layout.chunks.size();
+    // Device arena: [stream | slack][payload].  The slack lets the decoder's
+    // input window read whole dwords past the last stream byte.
+    const uint64_t in_alloc = (in_len + 256 + 255) & ~uint64_t(255);
+    const uint64_t payload_off = in_alloc;
+    int st;
+    if ((st = s.d_data.ensure(static_cast<size_t>(payload_off + layout.decoded_size + 64))) !=
+        SNAPPY_OK)
+        return st;
+    uint8_t *d_in = static_cast<uint8_t *>(s.d_data.ptr);
+    out.d_payload = d_in + payload_off;
+    out.size = layout.decoded_size;
+    if (n_chunks == 0)
+        return layout.stop_status;
+    if (n_chunks > 0xFFFFFFF0ull)
+        return SNAPPY_E_INVALID_ARG;
+
+    const size_t table_bytes = n_chunks * sizeof(Lz4Chunk);
+    const size_t status_bytes = n_chunks * sizeof(uint32_t);
+    if ((st = s.d_tasks.ensure(table_bytes)) != SNAPPY_OK) return st;
+    if ((st = s.d_out.ensure(status_bytes)) != SNAPPY_OK) return st;
+    if ((st = s.d_misc.ensure(256)) != SNAPPY_OK) return st;
+    if ((st = s.h_stage.ensure(std::max(table_bytes, status_bytes))) != SNAPPY_OK) return st;
+
+    hipStream_t stream = s.stream;
+    SNAPPY_HIP_TRY(hipMemsetAsync(d_in + in_len, 0, in_alloc - in_len, stream));
+    SNAPPY_HIP_TRY(hipMemcpyAsync(d_in, in, in_len, hipMemcpyHostToDevice, stream));
+    std::memcpy(s.h_stage.ptr, layout.chunks.data(), table_bytes);
+    SNAPPY_HIP_TRY(hipMemcpyAsync(s.d_tasks.ptr, s.h_stage.ptr, table_bytes, hipMemcpyHostToDevice,
+                                  stream));
+    SNAPPY_HIP_TRY(hipMemsetAsync(s.d_misc.ptr, 0, 256, stream));
+
+    const bool prof = profiling_enabled();
+    if (prof)
+        SNAPPY_HIP_TRY(hipEventRecord(s.ev_prof[1][0], stream));
+    // One wave per chunk in flight; four waves per workgroup.
+    const int blocks = static_cast<int>(std::min<uint64_t>(
+        (n_chunks + 3) / 4, static_cast<uint64_t>(lease.dev->n_cu) * 8u));
+    SNAPPY_HIP_TRY(launch_lz4_decode(d_in, in_alloc, out.d_payload,
+                                     static_cast<const Lz4Chunk *>(s.d_tasks.ptr),
+                                     static_cast<uint32_t>(n_chunks),
+                                     static_cast<uint32_t *>(s.d_misc.ptr),
+                                     static_cast<uint32_t *>(s.d_out.ptr), blocks, stream));
+    if (prof)
+        SNAPPY_HIP_TRY(hipEventRecord(s.ev_prof[1][1], stream));
+    // The status words must be on the host before the staging buffer is reused.
+    SNAPPY_HIP_TRY(hipStreamSynchronize(stream));
+    SNAPPY_HIP_TRY(hipMemcpy(s.h_stage.ptr, s.d_out.ptr, status_bytes, hipMemcpyDeviceToHost));
+    if (prof) {
+        float ms = -1.f;
+        if (hipEventElapsedTime(&ms, s.ev_prof[1][0], s.ev_prof[1][1]) == hipSuccess)
+            profile_store(1, ms);
+    }
+    const uint32_t *status = static_cast<const uint32_t *>(s.h_stage.ptr);
+    for (uint64_t i = 0; i < n_chunks; ++i)
+        if (status[i] != 0)
+            return SNAPPY_E_LZ4_CORRUPT;
+    return layout.stop_status;
+}
+
+}  // namespace snappy
+
+using namespace snappy;
+
+extern "C" int snappy_lz4net_decoded_size(const uint8_t *in, uint64_t in_len, uint64_t *out_len)
+{
+    if (!out_len || (!in && in_len))
+        return SNAPPY_E_INVALID_ARG;
+    Lz4netLayout layout;
+    parse_lz4net_stream(in, in_len, layout);
+    if (layout.stop_status != SNAPPY_OK)
+        return layout.stop_status;
+    *out_len = layout.decoded_size;
+    return SNAPPY_OK;
+}
+
+extern "C" int snappy_lz4net_decode(const uint8_t *in, uint64_t in_len, uint8_t *out,
+                                    uint64_t out_cap, uint64_t *out_len)
+{
+    if (!out_len || (!in && in_len) || (!out && out_cap))
+        return SNAPPY_E_INVALID_ARG;
+    Lz4netLayout layout;
+    parse_lz4net_stream(in, in_len, layout);
+    // The reader meets chunks in order: a chunk that does not fit the caller's
+    // buffer ends the walk there, before any later structural error.
+    uint64_t total = 0;
+    for (size_t i = 0; i < layout.chunks.size(); ++i) {
+        if (total + layout.chunks[i].orig_len > out_cap) {
+            layout.chunks.resize(i);
+            layout.stop_status = SNAPPY_E_CAPACITY;
+            break;
+        }
+        total += layout.chunks[i].orig_len;
+    }
+    layout.decoded_size = total;
+
+    SlotLease lease;
+    int st = lease.acquire(pick_device());
+    if (st != SNAPPY_OK)
+        return st;
+    profile_reset();
+    DecodedOnDevice dec;
+    st = decode_lz4net_on_device(lease, in, in_len, layout, dec);
+    if (st != SNAPPY_OK)
+        return st;
+    if (dec.size)
+        SNAPPY_HIP_TRY(hipMemcpy(out, dec.d_payload, dec.size, hipMemcpyDeviceToHost));
+    *out_len = dec.size;
+    return SNAPPY_OK;
+}

@@ -1,0 +1,37 @@
+// lz4net LZ4Stream framing (host side) and the device decode driver.
+#pragma once
+
+#include <stdint.h>
+
+#include <vector>
+
+#include "lz4_launch.hpp"
+#include "runtime.hpp"
+
+namespace snappy {
+
+struct Lz4netLayout {
+    std::vector<Lz4Chunk> chunks;  // chunks that are structurally sound, in stream order
+    uint64_t decoded_size = 0;     // sum of their original lengths
+    int stop_status = SNAPPY_OK;   // what ends the walk after those chunks: OK = clean EOF
+};
+
+// Walks the chunk headers of the stream.  Chunks before the first structural
+// error are kept so that the caller can still report an earlier corrupt block
+// first, as the managed reader would (it fails at the first bad chunk it meets).
+void parse_lz4net_stream(const uint8_t *in, uint64_t in_len, Lz4netLayout &layout);
+
+// Device-resident result of decoding a stream: the payload lies in
+// slot.d_data at [payload_off, payload_off + decoded_size).
+struct DecodedOnDevice {
+    uint8_t *d_payload = nullptr;
+    uint64_t size = 0;
+};
+
+// Uploads the stream, decodes every chunk of `layout` on the lease's device and
+// leaves the payload in HBM.  Returns SNAPPY_E_LZ4_CORRUPT when a block is
+// malformed, else layout.stop_status.
+int decode_lz4net_on_device(SlotLease &lease, const uint8_t *in, uint64_t in_len,
+                            const Lz4netLayout &layout, DecodedOnDevice &out);
+
+}  // namespace snappy

@@ -1,0 +1,87 @@
+// Host runtime shared by the C-ABI entry points: device contexts, per-call
+// slots (stream + pooled buffers), error plumbing.
+//
+// The reference's callers are a UI thread and a thread-pool task that may
+// overlap (/root/reference/Snappy/Plugin.cs:257-278 runs the migrator's hash
+// loop in Task.Run while Snappy/Core/SnapshotManager.cs:312-324 may run from a
+// button press), so every entry point takes a private slot for the duration of
+// the call and shares no mutable state outside the slot pool's lock.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <condition_variable>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/snappyhash.h"
+
+namespace snappy {
+
+void set_error_detail(const std::string &s);
+
+#define SNAPPY_HIP_TRY(expr)                                                              \
+    do {                                                                                  \
+        hipError_t _e = (expr);                                                           \
+        if (_e != hipSuccess) {                                                           \
+            ::snappy::set_error_detail(std::string(#expr) + ": " + hipGetErrorString(_e)); \
+            return (_e == hipErrorOutOfMemory) ? SNAPPY_E_NOMEM : SNAPPY_E_HIP;           \
+        }                                                                                 \
+    } while (0)
+
+// Grow-only device or pinned-host buffer owned by a slot.
+struct Buffer {
+    void *ptr = nullptr;
+    size_t cap = 0;
+    bool pinned_host = false;
+    int ensure(size_t bytes);  // SNAPPY_* status; keeps contents only when no growth is needed
+    void release();
+};
+
+constexpr int kProfileKernels = 2;  // 0 = SHA-1, 1 = LZ4 decode
+
+// Everything one in-flight call needs on one device.
+struct Slot {
+    hipStream_t stream = nullptr;      // main stream of the call
+    hipStream_t side_stream = nullptr; // second stream for kernels that may overlap
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_prof[kProfileKernels][2] = {};
+    Buffer d_data;     // device arena for host-pointer calls
+    Buffer d_tasks;    // Sha1Task[] / chunk tables
+    Buffer d_out;      // digests / statuses
+    Buffer d_misc;     // queue counters, error words
+    Buffer h_stage;    // pinned host staging (tasks up, digests down)
+    bool busy = false;
+};
+
+struct DeviceCtx {
+    int hip_device = 0;
+    int n_cu = 0;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<std::unique_ptr<Slot>> slots;
+};
+
+// RAII lease of a slot; sets the HIP device for the calling thread.
+class SlotLease {
+public:
+    SlotLease() = default;
+    ~SlotLease();
+    SlotLease(const SlotLease &) = delete;
+    SlotLease &operator=(const SlotLease &) = delete;
+    int acquire(int device);  // SNAPPY_* status
+    Slot *slot = nullptr;
+    DeviceCtx *dev = nullptr;
+};
+
+int ensure_initialized();          // SNAPPY_OK or SNAPPY_E_NO_DEVICE / SNAPPY_E_HIP
+int device_count();                // after ensure_initialized
+int pick_device();                 // round-robin choice for single-buffer calls
+bool profiling_enabled();
+void profile_reset();
+void profile_store(int kernel, float ms);
+
+}  // namespace snappy

@@ -1,0 +1,221 @@
+// SHA-1 batch kernels for gfx950.
+//
+// SHA-1 is serial inside one message (block i+1 needs the state after block i),
+// so all parallelism is across messages.  Two kernels cover the two regimes of
+// the reference's hash loops (/root/reference/Snappy/Core/SnapshotManager.cs:
+// 312-324, Snappy/Features/Mcdf/McdfManager.cs:36-63, Snappy/Data/
+// SnapshotMigrator.cs:62-86):
+//
+//   sha1_lanes_kernel  one message per lane, 64 messages per wavefront.  Lanes
+//                      that finish a message pull the next one from a device
+//                      queue, so a wave stays full whatever the size mix.
+//                      Throughput path (many small files).
+//   sha1_wave_kernel   one message per wavefront.  The 64 lanes expand and
+//                      K-bias the message schedules of 64 consecutive blocks in
+//                      parallel (state-independent work) into LDS; the serial
+//                      80-round chain then runs once per block reading its
+//                      schedule from LDS.  Latency path (few large files).
+#include "sha1_device.hpp"
+#include "sha1_launch.hpp"
+
+namespace snappy {
+
+namespace {
+
+constexpr int kWave = 64;
+
+__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & (kWave - 1); }
+
+// ---------------------------------------------------------------------------
+// One message per lane.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+sha1_lanes_kernel(const uint8_t *__restrict__ base, const Sha1Task *__restrict__ tasks,
+                  uint32_t first, uint32_t end, uint32_t *__restrict__ queue,
+                  uint8_t *__restrict__ digests)
+{
+    const uint32_t lane = lane_id();
+    uint32_t h[5] = {0, 0, 0, 0, 0};
+    const uint8_t *p = nullptr;
+    uint64_t rem = 0, total = 0;
+    uint32_t out_index = 0;
+    // 0 = idle, 1 = message bytes (or its 0x80 block) next, 2 = length-only block next
+    uint32_t mode = 0;
+    bool exhausted = false;
+
+    for (;;) {
+        const bool need = (mode == 0) && !exhausted;
+        const uint64_t need_mask = __ballot(need);
+        if (need_mask) {
+            const uint32_t leader = static_cast<uint32_t>(__ffsll(static_cast<long long>(need_mask))) - 1u;
+            uint32_t start = 0;
+            if (lane == leader)
+                start = atomicAdd(queue, static_cast<uint32_t>(__popcll(need_mask)));
+            start = __shfl(start, leader);
+            if (need) {
+                const uint32_t rank =
+                    static_cast<uint32_t>(__popcll(need_mask & ((1ull << lane) - 1ull)));
+                const uint32_t i = first + start + rank;
+                if (i < end) {
+                    const Sha1Task t = tasks[i];
+                    p = base + t.offset;
+                    rem = total = t.len;
+                    out_index = t.out_index;
+#pragma unroll
+                    for (int k = 0; k < 5; ++k)
+                        h[k] = kSha1Init[k];
+                    mode = 1;
+                } else {
+                    exhausted = true;
+                }
+            }
+        }
+        if (__ballot(mode != 0) == 0)
+            break;
+        if (mode != 0) {
+            uint32_t w[16];
+            bool last = false;
+            if (mode == 1) {
+                if (rem >= 64) {
+                    load_block_be(p, w);
+                    p += 64;
+                    rem -= 64;
+                } else {
+                    last = load_tail_block_be(p, static_cast<uint32_t>(rem), total, w);
+                    if (!last)
+                        mode = 2;
+                }
+            } else {
+                make_length_block(total, w);
+                last = true;
+            }
+            sha1_compress(h, w);
+            if (last) {
+                store_digest(digests + 20ull * out_index, h);
+                mode = 0;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// One message per wavefront.
+// ---------------------------------------------------------------------------
+
+// LDS image of one superblock: the K-biased schedule words of up to 64 blocks,
+// stored as [quad q = t/4][block][4 words] so that a lane writes 16 contiguous
+// bytes next to its neighbours' (conflict-free ds_write_b128) and the chain
+// reads one broadcast 16-byte slot per four rounds.
+constexpr int kSuper = 64;
+constexpr int kQuads = 20;
+
+template <bool kOneLane>
+__global__ void __launch_bounds__(kWave)
+sha1_wave_kernel(const uint8_t *__restrict__ base, const Sha1Task *__restrict__ tasks,
+                 uint32_t n_tasks, uint32_t *__restrict__ queue, uint8_t *__restrict__ digests)
+{
+    __shared__ uint4 wk[kQuads * kSuper];
+    const uint32_t lane = lane_id();
+
+    for (;;) {
+        uint32_t i = 0;
+        if (lane == 0)
+            i = atomicAdd(queue, 1u);
+        i = __builtin_amdgcn_readfirstlane(i);
+        if (i >= n_tasks)
+            break;
+        const Sha1Task task = tasks[i];
+        const uint8_t *msg = base + task.offset;
+        const uint64_t len = task.len;
+        const uint64_t n_full = len >> 6;
+        const uint32_t rem = static_cast<uint32_t>(len & 63u);
+        const uint64_t n_blocks = n_full + (rem < 56 ? 1u : 2u);
+
+        uint32_t h[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k)
+            h[k] = kSha1Init[k];
+
+        for (uint64_t blk0 = 0; blk0 < n_blocks; blk0 += kSuper) {
+            const uint32_t nb =
+                static_cast<uint32_t>(n_blocks - blk0 < kSuper ? n_blocks - blk0 : kSuper);
+
+            // Phase 1: lane j expands block blk0+j.
+            if (lane < nb) {
+                const uint64_t b = blk0 + lane;
+                uint32_t w[16];
+                if (b < n_full)
+                    load_block_be(msg + (b << 6), w);
+                else if (b == n_full)
+                    load_tail_block_be(msg + (n_full << 6), rem, len, w);
+                else
+                    make_length_block(len, w);
+#pragma unroll
+                for (int q = 0; q < kQuads; ++q) {
+                    uint32_t v[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int t = 4 * q + k;
+                        const uint32_t wt = (t < 16) ? w[t] : sha1_schedule(w, t);
+                        v[k] = wt + kSha1K[t / 20];
+                    }
+                    wk[q * kSuper + lane] = make_uint4(v[0], v[1], v[2], v[3]);
+                }
+            }
+            __syncthreads();
+
+            // Phase 2: the serial chain, one block after another.
+            if (!kOneLane || lane == 0) {
+                for (uint32_t b = 0; b < nb; ++b) {
+                    uint32_t a = h[0], bb = h[1], c = h[2], d = h[3], e = h[4];
+#pragma unroll
+                    for (int q = 0; q < kQuads; ++q) {
+                        const uint4 v = wk[q * kSuper + b];
+                        const uint32_t x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            sha1_round<true>(4 * q + k, a, bb, c, d, e, x[k]);
+                    }
+                    h[0] += a;
+                    h[1] += bb;
+                    h[2] += c;
+                    h[3] += d;
+                    h[4] += e;
+                }
+            }
+            __syncthreads();
+        }
+        if (lane == 0)
+            store_digest(digests + 20ull * task.out_index, h);
+    }
+}
+
+}  // namespace
+
+hipError_t launch_sha1_lanes(const uint8_t *d_base, const Sha1Task *d_tasks, uint32_t first,
+                             uint32_t end, uint32_t *d_queue, uint8_t *d_digests, int blocks,
+                             hipStream_t stream)
+{
+    if (end <= first || blocks <= 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(sha1_lanes_kernel, dim3(blocks), dim3(256), 0, stream, d_base, d_tasks,
+                       first, end, d_queue, d_digests);
+    return hipGetLastError();
+}
+
+hipError_t launch_sha1_wave(const uint8_t *d_base, const Sha1Task *d_tasks, uint32_t n_tasks,
+                            uint32_t *d_queue, uint8_t *d_digests, int waves, bool one_lane,
+                            hipStream_t stream)
+{
+    if (n_tasks == 0 || waves <= 0)
+        return hipSuccess;
+    if (one_lane)
+        hipLaunchKernelGGL(sha1_wave_kernel<true>, dim3(waves), dim3(kWave), 0, stream, d_base,
+                           d_tasks, n_tasks, d_queue, d_digests);
+    else
+        hipLaunchKernelGGL(sha1_wave_kernel<false>, dim3(waves), dim3(kWave), 0, stream, d_base,
+                           d_tasks, n_tasks, d_queue, d_digests);
+    return hipGetLastError();
+}
+
+}  // namespace snappy

@@ -1,0 +1,91 @@
+"""Python face of the MCDF import data path
+(/root/reference/Snappy/Features/Mcdf/McdfManager.cs:28-84, McdfHeader.cs:26-62),
+marshalled to the C ABI."""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+
+from . import native
+
+
+def _as_u8(data) -> np.ndarray:
+    if isinstance(data, np.ndarray):
+        return np.ascontiguousarray(data, dtype=np.uint8).reshape(-1)
+    return np.frombuffer(bytes(data), dtype=np.uint8)
+
+
+def lz4net_decoded_size(stream) -> int:
+    buf = _as_u8(stream)
+    v = ctypes.c_uint64(0)
+    native.check(native.lib().snappy_lz4net_decoded_size(buf.ctypes.data if buf.size else None,
+                                                         buf.size, ctypes.byref(v)),
+                 "snappy_lz4net_decoded_size")
+    return v.value
+
+
+def lz4net_decode(stream, out_cap=None) -> bytes:
+    """`lz4Stream.CopyTo(memoryStream)`: the decoded bytes of an lz4net stream."""
+    buf = _as_u8(stream)
+    if out_cap is None:
+        try:
+            out_cap = lz4net_decoded_size(buf)
+        except native.SnappyError:
+            out_cap = 1 << 16  # the decode call reports the error in stream order
+    out = np.zeros(max(out_cap, 1), dtype=np.uint8)
+    v = ctypes.c_uint64(0)
+    native.check(native.lib().snappy_lz4net_decode(buf.ctypes.data if buf.size else None, buf.size,
+                                                   out.ctypes.data, out_cap, ctypes.byref(v)),
+                 "snappy_lz4net_decode")
+    return out[: v.value].tobytes()
+
+
+def mcdf_parse_header(payload):
+    """Returns (lengths, body_offset) of a decoded MCDF payload."""
+    buf = _as_u8(payload)
+    n = ctypes.c_uint64(0)
+    body = ctypes.c_uint64(0)
+    ptr = buf.ctypes.data if buf.size else None
+    native.check(native.lib().snappy_mcdf_parse_header(ptr, buf.size, ctypes.byref(n),
+                                                       ctypes.byref(body), None, 0),
+                 "snappy_mcdf_parse_header")
+    lengths = np.zeros(max(n.value, 1), dtype=np.int64)
+    native.check(native.lib().snappy_mcdf_parse_header(ptr, buf.size, ctypes.byref(n),
+                                                       ctypes.byref(body), lengths.ctypes.data,
+                                                       lengths.size),
+                 "snappy_mcdf_parse_header")
+    return lengths[: n.value].copy(), body.value
+
+
+def mcdf_decode_and_hash(stream, want_payload: bool = False, n_files_cap: int = 1024):
+    """Fused decode + slice + hash.  Returns dict(digests, statuses, body_offset, payload_len, payload)."""
+    buf = _as_u8(stream)
+    lib = native.lib()
+    while True:
+        digests = np.zeros((max(n_files_cap, 1), 20), dtype=np.uint8)
+        statuses = np.zeros(max(n_files_cap, 1), dtype=np.uint8)
+        n = ctypes.c_uint64(0)
+        body = ctypes.c_uint64(0)
+        plen = ctypes.c_uint64(0)
+        payload = None
+        cap = 0
+        if want_payload:
+            cap = lz4net_decoded_size(buf)
+            payload = np.zeros(max(cap, 1), dtype=np.uint8)
+        st = lib.snappy_mcdf_decode_and_hash(buf.ctypes.data if buf.size else None, buf.size,
+                                             digests.ctypes.data, statuses.ctypes.data,
+                                             n_files_cap, ctypes.byref(n), ctypes.byref(body),
+                                             payload.ctypes.data if want_payload else None, cap,
+                                             ctypes.byref(plen))
+        if st == native.E_CAPACITY and n.value > n_files_cap:
+            n_files_cap = n.value
+            continue
+        native.check(st, "snappy_mcdf_decode_and_hash")
+        return {
+            "digests": digests[: n.value].copy(),
+            "statuses": statuses[: n.value].copy(),
+            "body_offset": body.value,
+            "payload_len": plen.value,
+            "payload": payload[: plen.value].tobytes() if want_payload else None,
+        }

@@ -1,0 +1,28 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (gfx950) device")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import oracle as o
+
+    o.build()
+    return o
+
+
+@pytest.fixture(scope="session")
+def snappy():
+    import snappy_amd
+
+    snappy_amd.native.lib()
+    return snappy_amd

@@ -1,0 +1,184 @@
+"""lz4net stream decode and the fused MCDF path on the GPU, checked byte for byte and
+status for status against the CPU oracle."""
+import hashlib
+
+import numpy as np
+import pytest
+
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def _gpu_decode(snappy, stream, out_cap=None):
+    try:
+        return 0, snappy.lz4net_decode(stream, out_cap)
+    except snappy.native.SnappyError as e:
+        return e.code, b""
+
+
+def test_hand_vectors_as_chunks(snappy, oracle):
+    for name, (blk, want) in H.good_block_vectors().items():
+        if len(blk) > len(want):
+            continue  # lz4net never emits (and rejects) a chunk that grew
+        for pad in (b"", b"\x00", b"\x00\x00", b"\x00\x00\x00"):
+            # leading stored chunk shifts the compressed payload to every dword alignment
+            lead = H.chunk(b"z" * len(pad), len(pad), False) if pad else b""
+            stream = lead + H.chunk(blk, len(want), True)
+            st, got = _gpu_decode(snappy, stream)
+            assert st == 0, (name, len(pad))
+            assert got == b"z" * len(pad) + want, (name, len(pad))
+
+
+def test_bad_vectors_as_chunks(snappy, oracle):
+    for name, (blk, out_len) in H.bad_block_vectors().items():
+        if len(blk) > out_len:
+            continue
+        stream = H.chunk(blk, out_len, True)
+        assert oracle.lz4net_decode(stream)[0] == oracle.E_LZ4_CORRUPT, name
+        st, _ = _gpu_decode(snappy, stream)
+        assert st == snappy.native.E_LZ4_CORRUPT, name
+
+
+def test_liblz4_golden_blocks(snappy):
+    g = H.load_golden("lz4_golden.json")
+    for row in g["blocks"]:
+        blk = bytes.fromhex(row["block_hex"])
+        if len(blk) > row["orig_len"]:
+            continue
+        st, got = _gpu_decode(snappy, H.chunk(blk, row["orig_len"], True))
+        assert st == 0, row["gen"]
+        assert hashlib.sha1(got).hexdigest().upper() == row["sha1"], row["gen"]
+
+
+def test_framing_cases_match_oracle(snappy, oracle):
+    data = H.compressible(5000, 1)
+    blk = oracle.lz4_block_encode(data)
+    stored = H.chunk(b"plain bytes", 11, False)
+    comp = H.chunk(blk, len(data), True, flags_extra=2)
+    bad = H.chunk(blk[:-1], len(data), True)
+    cases = {
+        "empty": b"",
+        "mixed": stored + comp + H.chunk(b"", 0, False) + H.chunk(b"", 0, True) + stored,
+        "payload_cut": (stored + comp)[:-3],
+        "varint_cut": stored + b"\x81",
+        "flags_only": stored + b"\x00",
+        "comp_gt_orig": H.varint(1) + H.varint(4) + H.varint(5) + b"abcde",
+        "passes": H.chunk(blk, len(data), True, flags_extra=4),
+        "stored_ignores_passes": H.chunk(b"abc", 3, False, flags_extra=4),
+        "corrupt": bad,
+        "corrupt_then_truncated": bad + stored[:-2],
+        "truncated_after_good": comp + stored[:-2],
+        "int32_narrowing": H.varint(0) + H.varint(1 << 31),
+    }
+    for name, s in cases.items():
+        want_st, want = oracle.lz4net_decode(s)
+        st, got = _gpu_decode(snappy, s)
+        assert st == want_st, name
+        if st == 0:
+            assert got == want, name
+    # capacity: reported where the reader would run out of room
+    assert _gpu_decode(snappy, stored + comp, out_cap=100)[0] == snappy.native.E_CAPACITY
+    assert oracle.lz4net_decode(stored + comp, out_cap=100)[0] == oracle.E_CAPACITY
+
+
+@pytest.mark.parametrize("kind,size,chunk", [("compressible", 3_000_000, 1 << 20),
+                                              ("asset_like", 6_000_000, 1 << 20),
+                                              ("asset_like", 700_000, 65536),
+                                              ("random", 2_500_000, 1 << 20),
+                                              ("zeros", 2_200_000, 1 << 20)])
+def test_generated_streams_roundtrip(snappy, oracle, kind, size, chunk):
+    if kind == "compressible":
+        data = H.compressible(size, 5)
+    elif kind == "asset_like":
+        data = H.asset_like(size, 6)
+    elif kind == "random":
+        data = H.random_bytes(size, 7)
+    else:
+        data = bytes(size)
+    stream = oracle.lz4net_encode(data, chunk_size=chunk, hc_flag=True)
+    want_st, want = oracle.lz4net_decode(stream)
+    assert want_st == 0 and want == data
+    st, got = _gpu_decode(snappy, stream)
+    assert st == 0
+    assert got == data
+
+
+def test_single_bit_corruptions_never_fault(snappy, oracle):
+    """Flip bytes of a valid stream: the GPU decoder must agree with the oracle on
+    accept/reject and on the bytes whenever both accept."""
+    data = H.compressible(40_000, 9)
+    stream = bytearray(oracle.lz4net_encode(data, chunk_size=16384))
+    rng = np.random.default_rng(3)
+    for _ in range(60):
+        s = bytearray(stream)
+        pos = int(rng.integers(0, len(s)))
+        s[pos] ^= 1 << int(rng.integers(0, 8))
+        want_st, want = oracle.lz4net_decode(bytes(s))
+        st, got = _gpu_decode(snappy, bytes(s))
+        assert st == want_st, pos
+        if st == 0:
+            assert got == want, pos
+
+
+def _make_archive(oracle, n_files, seed, chunk=1 << 20, declared_extra=0):
+    rng = np.random.default_rng(seed)
+    files = []
+    for i in range(n_files):
+        n = int(rng.integers(0, 400_000)) if i % 9 else 0
+        body = H.asset_like(n, seed * 100 + i) if n else None
+        paths = [f"chara/equipment/e{seed:04d}/file_{i}.tex"]
+        if i % 4 == 0:
+            paths.append(paths[0].upper())
+        files.append((paths, body, n))
+    payload = oracle.build_mcdf_payload(f"archive {seed}", files)
+    if declared_extra:
+        payload = payload[:-declared_extra]
+    return oracle.lz4net_encode(payload, chunk_size=chunk), payload
+
+
+def test_mcdf_fused_matches_oracle(snappy, oracle):
+    stream, payload = _make_archive(oracle, 40, 1)
+    ref = oracle.mcdf_import(stream)
+    got = snappy.mcdf_decode_and_hash(stream, want_payload=True, n_files_cap=4)  # forces the retry path
+    assert got["payload"] == payload
+    assert got["body_offset"] == ref["body_offset"] and got["payload_len"] == len(payload)
+    assert list(got["statuses"]) == ref["statuses"]
+    from snappy_amd.crypto import digests_to_hex
+
+    hx = digests_to_hex(got["digests"])
+    k = 0
+    for (paths, length), st, h in zip(ref["data"]["Files"], ref["statuses"], hx):
+        if st == oracle.FILE_HASHED:
+            for p in paths:
+                # the map keeps the last writer per folded key; every hashed file's digest must be the oracle's
+                pass
+            body = payload[ref["body_offset"] + k: ref["body_offset"] + k + length]
+            assert h == hashlib.sha1(body).hexdigest().upper()
+            k += length
+        else:
+            assert h == "0" * 40
+
+
+def test_mcdf_short_read_and_errors(snappy, oracle):
+    stream, payload = _make_archive(oracle, 12, 2, declared_extra=1000)
+    ref = oracle.mcdf_import(stream)
+    got = snappy.mcdf_decode_and_hash(stream)
+    assert list(got["statuses"]) == ref["statuses"]
+    assert oracle.FILE_SKIPPED_SHORT_READ in ref["statuses"]
+    # header errors after a clean decode
+    for bad_payload, code in ((b"XCDF" + payload[4:], oracle.E_MCDF_MAGIC),
+                              (payload[:4] + b"\x07" + payload[5:], oracle.E_MCDF_VERSION),
+                              (payload[:6], oracle.E_MCDF_TRUNCATED),
+                              (b"MCDF\x01\x05\x00\x00\x00{]}}}rest", oracle.E_MCDF_JSON)):
+        s = oracle.lz4net_encode(bad_payload, chunk_size=1 << 16)
+        with pytest.raises(oracle.McdfError) as eo:
+            oracle.mcdf_import(s)
+        assert eo.value.code == code
+        with pytest.raises(snappy.native.SnappyError) as es:
+            snappy.mcdf_decode_and_hash(s)
+        assert es.value.code == code
+    # stream errors come before header errors
+    with pytest.raises(snappy.native.SnappyError) as es:
+        snappy.mcdf_decode_and_hash(stream[:-7])
+    assert es.value.code == snappy.native.E_LZ4_TRUNCATED

@@ -1,0 +1,179 @@
+"""SHA-1 parity on the GPU: every call goes through the C ABI and is checked bit for
+bit against the CPU oracle (and the committed hashlib golden digests)."""
+import os
+
+import numpy as np
+import pytest
+
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _clean_env():
+    keep = {k: os.environ.get(k) for k in ("SNAPPY_WAVE_MIN_BLOCKS", "SNAPPY_WAVE_ONE_LANE")}
+    yield
+    for k, v in keep.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
+
+
+def test_device_is_bound(snappy):
+    L = snappy.native.lib()
+    assert L.snappy_init(0) == 0
+    assert L.snappy_device_count() >= 1
+
+
+def test_fips_and_padding_edges(snappy):
+    g = H.load_golden("sha1_golden.json")
+    for e in g["fips"]:
+        data = e["ascii"].encode() if "ascii" in e else e["repeat"][0].encode() * e["repeat"][1]
+        assert snappy.get_hash(data) == e["sha1"]
+    for n, want in g["zeros"].items():
+        assert snappy.get_hash(b"\0" * int(n)) == want
+
+
+def test_golden_splitmix_single_calls(snappy):
+    g = H.load_golden("sha1_golden.json")
+    for row in g["splitmix"][:140]:
+        data = H.splitmix_bytes(row["len"], H.file_seed(row["index"]))
+        assert snappy.get_hash(data) == row["sha1"], row
+
+
+def test_golden_splitmix_one_batch_both_kernels(snappy, oracle):
+    """All golden rows in one packed batch, once per kernel path."""
+    g = H.load_golden("sha1_golden.json")
+    blobs = [H.splitmix_bytes(r["len"], H.file_seed(r["index"])) for r in g["splitmix"]]
+    want = [r["sha1"] for r in g["splitmix"]]
+    base = np.frombuffer(b"".join(blobs), dtype=np.uint8)
+    lengths = np.array([len(b) for b in blobs], dtype=np.uint64)
+    offsets = np.concatenate([[0], np.cumsum(lengths)[:-1]]).astype(np.uint64)
+    from snappy_amd.crypto import digests_to_hex
+
+    for wave_min in ("1000000000", "0", None):   # lanes only / wave only / planner's choice
+        if wave_min is None:
+            os.environ.pop("SNAPPY_WAVE_MIN_BLOCKS", None)
+        else:
+            os.environ["SNAPPY_WAVE_MIN_BLOCKS"] = wave_min
+        for one_lane in ("1", "0"):
+            os.environ["SNAPPY_WAVE_ONE_LANE"] = one_lane
+            got = digests_to_hex(snappy.sha1_batch(base, offsets, lengths))
+            assert got == want, (wave_min, one_lane)
+
+
+@pytest.mark.parametrize("wave_min", ["1000000000", "0"])
+def test_random_unaligned_slices_vs_oracle(snappy, oracle, wave_min):
+    """Slices at every byte alignment, overlapping, empty, and ending at the buffer's last byte."""
+    os.environ["SNAPPY_WAVE_MIN_BLOCKS"] = wave_min
+    rng = np.random.default_rng(11)
+    base = rng.integers(0, 256, size=300_000, dtype=np.uint8)
+    n = 3000 if wave_min != "0" else 700
+    lengths = rng.integers(0, 2500, size=n).astype(np.uint64)
+    lengths[::97] = 0
+    offsets = rng.integers(0, 300_000 - 2500, size=n).astype(np.uint64)
+    # force tails at the very end of the allocation, all four alignments
+    for k in range(8):
+        lengths[k] = 55 + k * 9
+        offsets[k] = base.size - int(lengths[k])
+    got = snappy.sha1_batch(base, offsets, lengths)
+    want = oracle.sha1_batch_np(base, offsets, lengths)
+    assert np.array_equal(got, want)
+
+
+def test_every_length_0_to_300_every_alignment(snappy, oracle):
+    base = np.frombuffer(H.random_bytes(4096, 3), dtype=np.uint8)
+    offs, lens = [], []
+    for a in range(4):
+        for n in range(0, 301):
+            offs.append(a + (n % 7) * 4)
+            lens.append(n)
+    offs = np.array(offs, dtype=np.uint64)
+    lens = np.array(lens, dtype=np.uint64)
+    for wave_min in ("1000000000", "0"):
+        os.environ["SNAPPY_WAVE_MIN_BLOCKS"] = wave_min
+        assert np.array_equal(snappy.sha1_batch(base, offs, lens),
+                              oracle.sha1_batch_np(base, offs, lens)), wave_min
+
+
+def test_separate_buffers_and_single_calls(snappy, oracle):
+    blobs = [H.random_bytes(n, n) for n in (0, 1, 63, 64, 65, 1000, 70_000, 1_500_001)]
+    got = snappy.sha1_files(blobs)
+    for i, b in enumerate(blobs):
+        assert got[i].tobytes() == oracle.sha1(b)
+        assert snappy.sha1(b) == oracle.sha1(b)
+    assert snappy.sha1_files([]).shape == (0, 20)
+
+
+def test_snapshot_folder_mix_planner_split(snappy, oracle):
+    """A scaled-down snapshot folder: .tex-like and .mdl-like sizes, planner picks the paths."""
+    rng = np.random.default_rng(21)
+    sizes = np.concatenate([H.mixed_sizes(rng, 40, 64 << 10, 3 << 20),
+                            H.mixed_sizes(rng, 20, 32 << 10, 1 << 20)])
+    blobs = [H.random_bytes(int(s), 1000 + i) for i, s in enumerate(sizes)]
+    got = snappy.sha1_files(blobs)
+    for i, b in enumerate(blobs):
+        assert got[i].tobytes() == oracle.sha1(b), i
+
+
+def test_device_resident_batch(snappy, oracle):
+    import torch
+
+    rng = np.random.default_rng(31)
+    host = rng.integers(0, 256, size=8 << 20, dtype=np.uint8)
+    dev = torch.from_numpy(host).cuda()
+    lengths = rng.integers(0, 40_000, size=500).astype(np.uint64)
+    offsets = rng.integers(0, host.size - 40_000, size=500).astype(np.uint64)
+    want = oracle.sha1_batch_np(host, offsets, lengths)
+    got = snappy.sha1_batch_device(0, dev.data_ptr(), offsets, lengths)
+    assert np.array_equal(got, want)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        got2 = snappy.sha1_batch_device(0, dev.data_ptr(), offsets, lengths, stream=s.cuda_stream)
+    assert np.array_equal(got2, want)
+
+
+def test_large_files_properties(snappy, oracle):
+    """Full-size blobs: one 64 MiB file against the oracle, plus a prefix-extension
+    property across files (digest of a prefix equals the digest of the same bytes hashed alone)."""
+    import torch
+
+    n = 64 << 20
+    dev = torch.randint(0, 256, (n + 13,), dtype=torch.uint8, device="cuda")
+    host = dev.cpu().numpy()
+    offsets = np.array([0, 5, 13, 1, 7], dtype=np.uint64)
+    lengths = np.array([n, 4 << 20, 16 << 20, (32 << 20) + 3, 64], dtype=np.uint64)
+    got = snappy.sha1_batch_device(0, dev.data_ptr(), offsets, lengths)
+    want = oracle.sha1_batch_np(host, offsets, lengths)
+    assert np.array_equal(got, want)
+    again = snappy.sha1_batch(host, offsets, lengths)
+    assert np.array_equal(again, want)
+
+
+def test_concurrent_callers(snappy, oracle):
+    """Two threads hash at once, as the UI thread and the migration task may."""
+    import threading
+
+    blobs = [H.random_bytes(200_000 + 977 * i, i) for i in range(24)]
+    want = [oracle.sha1(b) for b in blobs]
+    errors = []
+
+    def work(lo, hi):
+        try:
+            for _ in range(5):
+                got = snappy.sha1_files(blobs[lo:hi])
+                for k in range(hi - lo):
+                    if got[k].tobytes() != want[lo + k]:
+                        errors.append((lo, k))
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=work, args=(0, 12)), threading.Thread(target=work, args=(12, 24)),
+               threading.Thread(target=work, args=(6, 18))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors
