@@ -22,6 +22,7 @@
 // length.  Every read and write is bounds-checked against the chunk, so a
 // corrupt stream yields a status word, never a stray access.
 #include "lz4_launch.hpp"
+#include "wave_util.hpp"
 
 namespace snappy {
 
@@ -299,10 +300,7 @@ lz4_decode_kernel(const uint8_t *__restrict__ in_base, uint64_t in_alloc, uint8_
 {
     const uint32_t lane = threadIdx.x & (kWave - 1);
     for (;;) {
-        uint32_t i = 0;
-        if (lane == 0)
-            i = atomicAdd(queue, 1u);
-        i = uni(i);
+        const uint32_t i = wave_claim(queue, 1u, lane);
         if (i >= n_chunks)
             break;
         const Lz4Chunk ck = chunks[i];
@@ -312,8 +310,8 @@ lz4_decode_kernel(const uint8_t *__restrict__ in_base, uint64_t in_alloc, uint8_
         } else {
             copy_run(out_base + ck.out_off, in_base + ck.in_off, ck.orig_len, lane);
         }
-        if (lane == 0)
-            status[i] = ok ? 0u : 1u;
+        // Every lane stores the same word: no lane-0-only tail (see wave_claim).
+        status[i] = ok ? 0u : 1u;
     }
 }
 

@@ -124,7 +124,6 @@ int run_sha1_plan(SlotLease &lease, const uint8_t *d_base, const Sha1Plan &plan,
     if (prof)
         SNAPPY_HIP_TRY(hipEventRecord(s.ev_prof[0][0], stream));
 
-    const bool one_lane = env_long("SNAPPY_WAVE_ONE_LANE", 1) != 0;
     const int wave_groups =
         static_cast<int>(std::min<uint64_t>(n_wave, static_cast<uint64_t>(lease.dev->n_cu) * 8u));
     const uint32_t n_lane = n_all - n_wave;
@@ -138,14 +137,14 @@ int run_sha1_plan(SlotLease &lease, const uint8_t *d_base, const Sha1Plan &plan,
         SNAPPY_HIP_TRY(hipEventRecord(s.ev_fork, stream));
         SNAPPY_HIP_TRY(hipStreamWaitEvent(s.side_stream, s.ev_fork, 0));
         SNAPPY_HIP_TRY(launch_sha1_wave(d_base, d_tasks, n_wave, q_wave, d_digests, wave_groups,
-                                        one_lane, s.side_stream));
+                                        s.side_stream));
         SNAPPY_HIP_TRY(launch_sha1_lanes(d_base, d_tasks, n_wave, n_all, q_lane, d_digests,
                                          lane_blocks, stream));
         SNAPPY_HIP_TRY(hipEventRecord(s.ev_join, s.side_stream));
         SNAPPY_HIP_TRY(hipStreamWaitEvent(stream, s.ev_join, 0));
     } else if (n_wave > 0) {
         SNAPPY_HIP_TRY(launch_sha1_wave(d_base, d_tasks, n_wave, q_wave, d_digests, wave_groups,
-                                        one_lane, stream));
+                                        stream));
     } else {
         SNAPPY_HIP_TRY(launch_sha1_lanes(d_base, d_tasks, 0, n_all, q_lane, d_digests, lane_blocks,
                                          stream));

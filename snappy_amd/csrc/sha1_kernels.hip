@@ -17,12 +17,14 @@
 //                      schedule from LDS.  Latency path (few large files).
 #include "sha1_device.hpp"
 #include "sha1_launch.hpp"
+#include "wave_util.hpp"
 
 namespace snappy {
 
 namespace {
 
 constexpr int kWave = 64;
+constexpr uint32_t kLaneBatch = 64;  // tasks a wave claims from the queue at a time
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & (kWave - 1); }
 
@@ -41,34 +43,42 @@ sha1_lanes_kernel(const uint8_t *__restrict__ base, const Sha1Task *__restrict__
     uint32_t out_index = 0;
     // 0 = idle, 1 = message bytes (or its 0x80 block) next, 2 = length-only block next
     uint32_t mode = 0;
-    bool exhausted = false;
+    // The wave claims task indices from the device queue kLaneBatch at a time and
+    // hands them to its idle lanes from this pool (all three values are uniform).
+    uint32_t pool_next = 0, pool_end = 0;
+    bool queue_empty = false;
 
     for (;;) {
-        const bool need = (mode == 0) && !exhausted;
-        const uint64_t need_mask = __ballot(need);
-        if (need_mask) {
-            const uint32_t leader = static_cast<uint32_t>(__ffsll(static_cast<long long>(need_mask))) - 1u;
-            uint32_t start = 0;
-            if (lane == leader)
-                start = atomicAdd(queue, static_cast<uint32_t>(__popcll(need_mask)));
-            start = __shfl(start, leader);
-            if (need) {
-                const uint32_t rank =
-                    static_cast<uint32_t>(__popcll(need_mask & ((1ull << lane) - 1ull)));
-                const uint32_t i = first + start + rank;
-                if (i < end) {
-                    const Sha1Task t = tasks[i];
-                    p = base + t.offset;
-                    rem = total = t.len;
-                    out_index = t.out_index;
-#pragma unroll
-                    for (int k = 0; k < 5; ++k)
-                        h[k] = kSha1Init[k];
-                    mode = 1;
-                } else {
-                    exhausted = true;
+        for (;;) {
+            const uint64_t need_mask = __ballot(mode == 0);
+            if (need_mask == 0)
+                break;
+            if (pool_next >= pool_end) {
+                if (queue_empty)
+                    break;
+                const uint32_t start = first + wave_claim(queue, kLaneBatch, lane);
+                if (start >= end) {
+                    queue_empty = true;
+                    break;
                 }
+                pool_next = start;
+                pool_end = (end - start < kLaneBatch) ? end : start + kLaneBatch;
             }
+            const uint32_t rank =
+                static_cast<uint32_t>(__popcll(need_mask & ((1ull << lane) - 1ull)));
+            const uint32_t i = pool_next + rank;
+            if (mode == 0 && i < pool_end) {
+                const Sha1Task t = tasks[i];
+                p = base + t.offset;
+                rem = total = t.len;
+                out_index = t.out_index;
+#pragma unroll
+                for (int k = 0; k < 5; ++k)
+                    h[k] = kSha1Init[k];
+                mode = 1;
+            }
+            const uint32_t taken = static_cast<uint32_t>(__popcll(need_mask));
+            pool_next = (pool_end - pool_next < taken) ? pool_end : pool_next + taken;
         }
         if (__ballot(mode != 0) == 0)
             break;
@@ -109,7 +119,6 @@ sha1_lanes_kernel(const uint8_t *__restrict__ base, const Sha1Task *__restrict__
 constexpr int kSuper = 64;
 constexpr int kQuads = 20;
 
-template <bool kOneLane>
 __global__ void __launch_bounds__(kWave)
 sha1_wave_kernel(const uint8_t *__restrict__ base, const Sha1Task *__restrict__ tasks,
                  uint32_t n_tasks, uint32_t *__restrict__ queue, uint8_t *__restrict__ digests)
@@ -118,10 +127,7 @@ sha1_wave_kernel(const uint8_t *__restrict__ base, const Sha1Task *__restrict__ 
     const uint32_t lane = lane_id();
 
     for (;;) {
-        uint32_t i = 0;
-        if (lane == 0)
-            i = atomicAdd(queue, 1u);
-        i = __builtin_amdgcn_readfirstlane(i);
+        const uint32_t i = wave_claim(queue, 1u, lane);
         if (i >= n_tasks)
             break;
         const Sha1Task task = tasks[i];
@@ -164,8 +170,10 @@ sha1_wave_kernel(const uint8_t *__restrict__ base, const Sha1Task *__restrict__ 
             }
             __syncthreads();
 
-            // Phase 2: the serial chain, one block after another.
-            if (!kOneLane || lane == 0) {
+            // Phase 2: the serial chain, one block after another.  Every lane runs it
+            // on the same broadcast words: a wave issues one instruction per ~4.5
+            // cycles whatever its EXEC mask, and a one-lane mask measured slower.
+            {
                 for (uint32_t b = 0; b < nb; ++b) {
                     uint32_t a = h[0], bb = h[1], c = h[2], d = h[3], e = h[4];
 #pragma unroll
@@ -185,8 +193,8 @@ sha1_wave_kernel(const uint8_t *__restrict__ base, const Sha1Task *__restrict__ 
             }
             __syncthreads();
         }
-        if (lane == 0)
-            store_digest(digests + 20ull * task.out_index, h);
+        // All lanes hold the same state and store the same bytes.
+        store_digest(digests + 20ull * task.out_index, h);
     }
 }
 
@@ -204,17 +212,12 @@ hipError_t launch_sha1_lanes(const uint8_t *d_base, const Sha1Task *d_tasks, uin
 }
 
 hipError_t launch_sha1_wave(const uint8_t *d_base, const Sha1Task *d_tasks, uint32_t n_tasks,
-                            uint32_t *d_queue, uint8_t *d_digests, int waves, bool one_lane,
-                            hipStream_t stream)
+                            uint32_t *d_queue, uint8_t *d_digests, int waves, hipStream_t stream)
 {
     if (n_tasks == 0 || waves <= 0)
         return hipSuccess;
-    if (one_lane)
-        hipLaunchKernelGGL(sha1_wave_kernel<true>, dim3(waves), dim3(kWave), 0, stream, d_base,
-                           d_tasks, n_tasks, d_queue, d_digests);
-    else
-        hipLaunchKernelGGL(sha1_wave_kernel<false>, dim3(waves), dim3(kWave), 0, stream, d_base,
-                           d_tasks, n_tasks, d_queue, d_digests);
+    hipLaunchKernelGGL(sha1_wave_kernel, dim3(waves), dim3(kWave), 0, stream, d_base, d_tasks,
+                       n_tasks, d_queue, d_digests);
     return hipGetLastError();
 }
 

@@ -17,7 +17,6 @@ hipError_t launch_sha1_lanes(const uint8_t *d_base, const Sha1Task *d_tasks, uin
 // Tasks [0, n_tasks) of d_tasks, one message per wavefront.  *d_queue must be
 // zero at launch.  `waves` single-wave workgroups (20 KiB of LDS each).
 hipError_t launch_sha1_wave(const uint8_t *d_base, const Sha1Task *d_tasks, uint32_t n_tasks,
-                            uint32_t *d_queue, uint8_t *d_digests, int waves, bool one_lane,
-                            hipStream_t stream);
+                            uint32_t *d_queue, uint8_t *d_digests, int waves, hipStream_t stream);
 
 }  // namespace snappy

@@ -76,6 +76,14 @@ def lib() -> ctypes.CDLL:
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build it with `python -m snappy_amd.build` "
                 "(there is no fallback implementation)")
+        # PyTorch ships its own copy of the HIP runtime (same soname).  Two copies in
+        # one process cannot both open the GPU, so when torch is importable it goes
+        # first and this library binds to the runtime torch brought in; device
+        # pointers and streams from torch are then valid here.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = ctypes.CDLL(LIB_PATH)
         for name, restype, argtypes in SYMBOLS:
             fn = getattr(L, name)  # AttributeError if the library lacks a declared symbol

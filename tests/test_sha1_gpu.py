@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(autouse=True)
 def _clean_env():
-    keep = {k: os.environ.get(k) for k in ("SNAPPY_WAVE_MIN_BLOCKS", "SNAPPY_WAVE_ONE_LANE")}
+    keep = {k: os.environ.get(k) for k in ("SNAPPY_WAVE_MIN_BLOCKS",)}
     yield
     for k, v in keep.items():
         if v is None:
@@ -58,10 +58,8 @@ def test_golden_splitmix_one_batch_both_kernels(snappy, oracle):
             os.environ.pop("SNAPPY_WAVE_MIN_BLOCKS", None)
         else:
             os.environ["SNAPPY_WAVE_MIN_BLOCKS"] = wave_min
-        for one_lane in ("1", "0"):
-            os.environ["SNAPPY_WAVE_ONE_LANE"] = one_lane
-            got = digests_to_hex(snappy.sha1_batch(base, offsets, lengths))
-            assert got == want, (wave_min, one_lane)
+        got = digests_to_hex(snappy.sha1_batch(base, offsets, lengths))
+        assert got == want, wave_min
 
 
 @pytest.mark.parametrize("wave_min", ["1000000000", "0"])
