@@ -1,0 +1,261 @@
+#!/usr/bin/env python3
+"""Benchmark of the asset-hashing hot path on MI355X.
+
+One "step" = one pass of the hot path over one batch of synthetic assets that
+already sit in HBM: `snappy_sha1_batch_device` over the whole corpus (host
+tables in, digests back on the host).  The default workload is the large-blob
+corpus: sizes uniform in [4 MiB, 64 MiB] drawn until they sum to 8 GiB.
+
+With N > 1 ranks (launched by torch.distributed.run, one rank per GPU) every
+rank hashes its own corpus of that shape (weak scaling; files are independent,
+so there is no data-path collective).  The timed region is bracketed by a
+barrier and a device synchronize; the slowest rank's time counts.
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+GB = 1e9
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak
+MASK = (1 << 64) - 1
+
+
+def padded_blocks(lengths: np.ndarray) -> np.ndarray:
+    return (lengths.astype(np.uint64) + 8) // 64 + 1
+
+
+def make_sizes(workload: str, rng: np.random.Generator, scale: float):
+    """File sizes of one rank's corpus."""
+    if workload == "blobs":       # 4-64 MiB texture-sized blobs, 8 GiB in all
+        target = int((8 << 30) * scale)
+        sizes = []
+        total = 0
+        while total < target:
+            s = int(rng.integers(4 << 20, (64 << 20) + 1))
+            sizes.append(s)
+            total += s
+        return np.array(sizes, dtype=np.uint64)
+    if workload == "small":       # 10^6 files of 4-32 KB, not multiples of 64
+        n = int(1_000_000 * scale)
+        return rng.integers(4096, 32769, size=n).astype(np.uint64)
+    if workload == "folder":      # one saved snapshot folder, ~200 MB of .tex/.mdl sizes
+        tex = np.exp(rng.uniform(np.log(64 << 10), np.log(22 << 20), size=120))
+        mdl = np.exp(rng.uniform(np.log(32 << 10), np.log(6 << 20), size=40))
+        s = np.concatenate([tex, mdl])
+        s = s * (200e6 * scale / s.sum())
+        return np.maximum(s.astype(np.uint64), 1)
+    raise SystemExit(f"unknown workload {workload}")
+
+
+def fill_random(torch, n_bytes: int, device, seed: int):
+    """Random bytes resident in HBM (SHA-1 timing does not depend on content)."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    buf = torch.empty(n_bytes + 256, dtype=torch.uint8, device=device)
+    step = 1 << 30
+    for lo in range(0, n_bytes + 256, step):
+        hi = min(lo + step, n_bytes + 256)
+        # int32 words: 4 random bytes each
+        words = torch.randint(-(1 << 31), (1 << 31) - 1, ((hi - lo + 3) // 4,), dtype=torch.int32,
+                              device=device, generator=g)
+        buf[lo:hi] = words.view(torch.uint8)[: hi - lo]
+        del words
+    return buf
+
+
+def cpu_baseline(host_sample: np.ndarray, offsets, lengths):
+    """The reference loop (read -> SHA-1 -> uppercase hex, sequential, one thread:
+    Snappy/Core/SnapshotManager.cs:312-324) timed with the CPU oracle on a bounded sample."""
+    from oracle import oracle
+
+    L = oracle.lib()
+    n = len(offsets)
+    off = np.ascontiguousarray(offsets, dtype=np.uint64)
+    ln = np.ascontiguousarray(lengths, dtype=np.uint64)
+    out = np.zeros((n, 20), dtype=np.uint8)
+    t0 = time.perf_counter()
+    L.oracle_sha1_batch(host_sample.ctypes.data, off.ctypes.data, ln.ctypes.data, n, out.ctypes.data)
+    dt = time.perf_counter() - t0
+    res = {"value": float(ln.sum()) / dt / GB, "unit": "GB/s", "cores": 1, "kind": "port",
+           "sample": f"{n} files, {int(ln.sum())} bytes of the same corpus, sequential loop, "
+                     "scalar C restatement of Crypto.GetHash (oracle/sha1_oracle.c)"}
+    # What .NET itself calls on Linux: OpenSSL's SHA1 (uses SHA-NI when the CPU has it).
+    try:
+        crypto = ctypes.CDLL("libcrypto.so.3")
+        crypto.SHA1.restype = ctypes.c_void_p
+        crypto.SHA1.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+        md = (ctypes.c_uint8 * 20)()
+        base = host_sample.ctypes.data
+        t0 = time.perf_counter()
+        for i in range(n):
+            crypto.SHA1(base + int(off[i]), int(ln[i]), md)
+        dt2 = time.perf_counter() - t0
+        res["openssl_1core_value"] = float(ln.sum()) / dt2 / GB
+        ok = bytes(md) == out[n - 1].tobytes()
+        res["openssl_agrees_with_port"] = bool(ok)
+    except OSError:
+        pass
+    return res, out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="blobs", choices=["blobs", "small", "folder"])
+    ap.add_argument("--scale", type=float, default=1.0, help="shrink or grow the corpus")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-gb", type=float, default=4.0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+
+    import torch
+
+    import snappy_amd
+    from snappy_amd import native
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device is visible")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+
+        dist = dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # Control plane only (barrier, max of timings): no data-path collective exists.
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    lib = native.lib()
+    native.check(lib.snappy_init(0), "snappy_init")
+    lib.snappy_profile_enable(1)
+
+    rng = np.random.default_rng(0x534E4150 + rank)
+    lengths = make_sizes(args.workload, rng, args.scale)
+    offsets = np.concatenate([[0], np.cumsum(lengths)[:-1]]).astype(np.uint64)
+    total_bytes = int(lengths.sum())
+    algo_bytes = int(padded_blocks(lengths).sum()) * 64
+    buf = fill_random(torch, total_bytes, device, seed=1234 + rank)
+    torch.cuda.synchronize()
+    n = len(lengths)
+    digests = np.zeros((n, 20), dtype=np.uint8)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        native.check(lib.snappy_sha1_batch_device(local_rank, buf.data_ptr(), offsets.ctypes.data,
+                                                  lengths.ctypes.data, n, digests.ctypes.data,
+                                                  stream), "snappy_sha1_batch_device")
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    kernel_ms = []
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        kernel_ms.append(lib.snappy_profile_last_ms(0))
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        tot = torch.tensor([float(total_bytes)], dtype=torch.float64)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        job_bytes = float(tot.item())
+    else:
+        job_bytes = float(total_bytes)
+
+    if rank != 0:
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    ms_per_step = elapsed / args.steps * 1e3
+    value = job_bytes * args.steps / elapsed / GB
+    k_ms = float(np.mean(kernel_ms))
+    achieved = algo_bytes / (k_ms * 1e-3) / GB
+    max_blocks = int(padded_blocks(lengths).max())
+    out = {
+        "metric": "GB/s of mod assets hashed (+LZ4-decoded) per GPU and per node, kernel & e2e",
+        "value": value,
+        "unit": "GB/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u32",
+        "data": "synthetic",
+        "config": {
+            "workload": {"blobs": "8 GiB corpus of 4-64 MiB blobs per GPU, SHA-1, inputs resident in HBM",
+                         "small": "10^6 files of 4-32 KB per GPU, SHA-1, inputs resident in HBM",
+                         "folder": "one snapshot folder (160 files, ~200 MB), SHA-1, inputs resident in HBM"}[args.workload],
+            "files_per_gpu": n,
+            "bytes_per_gpu": total_bytes,
+            "largest_file_bytes": int(lengths.max()),
+            "parallelism": f"files sharded over {world} GPU(s), host dispatch, no collective",
+        },
+        "roofline": {
+            "bound": "hbm",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "traffic": None,
+            "kernel": "sha1_wave_kernel + sha1_lanes_kernel (run side by side)",
+            "kernel_ms": k_ms,
+            "algorithmic_bytes_per_launch": algo_bytes,
+            # SHA-1 is serial inside a file: a batch cannot finish before its largest
+            # file has run its chain, whatever the bandwidth.
+            "serial_chain_blocks": max_blocks,
+            "chain_ns_per_block": k_ms * 1e6 / max_blocks,
+        },
+    }
+
+    if not args.no_cpu_baseline:
+        # Bounded sample: the first files of rank 0's corpus up to the sample size.
+        cap = int(args.cpu_sample_gb * GB)
+        k = max(1, int(np.searchsorted(np.cumsum(lengths), cap, side="right")))
+        k = min(k, n)
+        sample_bytes = int(offsets[k - 1] + lengths[k - 1])
+        host = buf[:sample_bytes].cpu().numpy()
+        base, ref = cpu_baseline(host, offsets[:k], lengths[:k])
+        out["cpu_baseline"] = base
+        out["digests_match_cpu_oracle"] = bool(np.array_equal(ref, digests[:k]))
+        if not out["digests_match_cpu_oracle"]:
+            print("ERROR: GPU digests differ from the CPU oracle", file=sys.stderr)
+    print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if out.get("digests_match_cpu_oracle") is False:
+        sys.exit(1)
+
+
+if __name__ == "__main__":
+    main()

@@ -16,11 +16,16 @@ namespace snappy {
 
 namespace {
 
-// Measured cost model (cycles per 64-byte block on one wavefront's issue
-// stream) used only to split a batch between the two kernels.
-constexpr double kCyclesPerBlockWave = 1750.0;  // one message per wave
-constexpr double kCyclesPerBlockLane = 2600.0;  // one message per lane
-constexpr double kIssueCyclesPerBlockLane = 2.0 * 650.0 / 64.0;  // SIMD cycles, 64 messages/wave
+// Measured cost model, used only to split a batch between the two kernels:
+// nanoseconds one message spends per 64-byte block when its wavefront has a
+// SIMD to itself (both paths issue one instruction per ~4.2 cycles; the wave
+// path has 412 instructions per block on the chain, the lane path ~650 plus
+// what its 63 neighbours' tails cost).
+constexpr double kNsPerBlockWave = 714.0;
+constexpr double kNsPerBlockLane = 1300.0;
+// SIMD time one block costs on the lane path when a SIMD is saturated with
+// waves (64 messages share an instruction stream at ~2.5 cycles/instruction).
+constexpr double kSimdNsPerBlockLane = 650.0 * 2.5 / 64.0 / 2.4;
 
 inline uint64_t padded_blocks(uint64_t len) { return (len + 8) / 64 + 1; }
 
@@ -71,19 +76,20 @@ void build_sha1_plan(const uint64_t *offsets, const uint64_t *lengths, uint64_t 
     }
     plan.total_blocks = total_blocks;
 
-    // Split: the batch cannot finish before its largest message has run its
-    // serial chain on the faster (wave) path, nor before the lane path has
-    // issued all its blocks.  Messages that would outlast ~3/4 of that bound on
-    // the lane path go to the wave path, largest first.
-    const double n_simd = 4.0 * n_cu;
-    const double t_star = std::max(static_cast<double>(max_blocks) * kCyclesPerBlockWave,
-                                   static_cast<double>(total_blocks) * kIssueCyclesPerBlockLane /
-                                       n_simd);
-    double thr_blocks = 0.75 * t_star / kCyclesPerBlockLane;
+    // Split.  The batch cannot finish before its largest message has run its
+    // serial chain on the faster (wave) path, nor before the lane path has issued
+    // all its blocks.  A message goes to the wave path when the lane path would
+    // keep it past ~80 % of that bound; when there are no more messages than
+    // SIMDs every message gets a wave (and a SIMD) of its own.
+    const uint64_t n_simd = 4ull * static_cast<uint64_t>(n_cu);
+    const double t_star = std::max(static_cast<double>(max_blocks) * kNsPerBlockWave,
+                                   static_cast<double>(total_blocks) * kSimdNsPerBlockLane /
+                                       static_cast<double>(n_simd));
+    double thr_blocks = (n <= n_simd) ? 0.0 : 0.8 * t_star / kNsPerBlockLane;
     const long forced = env_long("SNAPPY_WAVE_MIN_BLOCKS", -1);  // tuning/testing override
     if (forced >= 0)
         thr_blocks = static_cast<double>(forced);
-    const uint64_t max_wave_tasks = static_cast<uint64_t>(n_cu) * 8u;
+    const uint64_t max_wave_tasks = 2 * n_simd;
     uint32_t n_wave = 0;
     while (n_wave < n && n_wave < max_wave_tasks &&
            static_cast<double>(padded_blocks(plan.tasks[n_wave].len)) > thr_blocks)
@@ -127,7 +133,7 @@ int run_sha1_plan(SlotLease &lease, const uint8_t *d_base, const Sha1Plan &plan,
     const int wave_groups =
         static_cast<int>(std::min<uint64_t>(n_wave, static_cast<uint64_t>(lease.dev->n_cu) * 8u));
     const uint32_t n_lane = n_all - n_wave;
-    const long blocks_per_cu = std::max(1L, env_long("SNAPPY_LANE_BLOCKS_PER_CU", 4));
+    const long blocks_per_cu = std::max(1L, env_long("SNAPPY_LANE_BLOCKS_PER_CU", 8));
     const int lane_blocks = static_cast<int>(std::min<uint64_t>(
         (static_cast<uint64_t>(n_lane) + 255) / 256,
         static_cast<uint64_t>(lease.dev->n_cu) * static_cast<uint64_t>(blocks_per_cu)));

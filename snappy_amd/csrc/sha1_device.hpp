@@ -101,15 +101,12 @@ __device__ __forceinline__ uint32_t be_selector(uint32_t shift)
     return 0x00010203u + shift * 0x01010101u;
 }
 
-// Loads the 64 message bytes at p (any byte alignment) as 16 big-endian words.
-// Reads the aligned dwords that overlap [p, p+64): 16 of them when p is
-// dword-aligned, 17 otherwise, so no byte outside a dword that holds message
-// bytes is touched.
-__device__ __forceinline__ void load_block_be(const uint8_t *p, uint32_t (&w)[16])
+// Loads the aligned dwords that overlap the 64 message bytes at p: 16 of them
+// when p is dword-aligned (shift == 0), 17 otherwise, so no byte outside a dword
+// that holds message bytes is touched.  shift = address of p modulo 4.
+__device__ __forceinline__ void load_block_raw(const uint8_t *p, uint32_t shift, uint32_t (&d)[17])
 {
-    const uint32_t shift = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(p) & 3u);
     const uint32_t *q = reinterpret_cast<const uint32_t *>(p - shift);
-    uint32_t d[17];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         uint32_t v[4];
@@ -120,10 +117,26 @@ __device__ __forceinline__ void load_block_be(const uint8_t *p, uint32_t (&w)[16
         d[4 * i + 3] = v[3];
     }
     d[16] = q[shift ? 16 : 15];
+}
+
+// Turns those dwords into the block's 16 big-endian words: one v_perm_b32 per
+// word does the byte swap and the sub-dword shift together.
+__device__ __forceinline__ void raw_block_to_be(const uint32_t (&d)[17], uint32_t shift,
+                                                uint32_t (&w)[16])
+{
     const uint32_t sel = be_selector(shift);
 #pragma unroll
     for (int t = 0; t < 16; ++t)
         w[t] = __builtin_amdgcn_perm(d[t + 1], d[t], sel);
+}
+
+// The 64 message bytes at p (any byte alignment) as 16 big-endian words.
+__device__ __forceinline__ void load_block_be(const uint8_t *p, uint32_t (&w)[16])
+{
+    const uint32_t shift = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(p) & 3u);
+    uint32_t d[17];
+    load_block_raw(p, shift, d);
+    raw_block_to_be(d, shift, w);
 }
 
 // Builds a padding block from the last `rem` (0..63) message bytes at p.
@@ -138,13 +151,22 @@ __device__ __forceinline__ bool load_tail_block_be(const uint8_t *p, uint32_t re
     const uint32_t *q = reinterpret_cast<const uint32_t *>(p - shift);
     const uint32_t sel = be_selector(shift);
     // Dword i (from q) overlaps the message iff rem > 0 and 4*i < shift + rem.
-    const uint32_t span = rem ? shift + rem : 0u;
-    uint32_t lo = (span > 0) ? q[0] : 0u;
+    // All 17 loads are issued together; indices past the last overlapping dword
+    // are clamped onto it (their bytes are masked off below).
+    uint32_t d[17];
+    if (rem) {
+        const uint32_t last_dword = (shift + rem - 1u) >> 2;
+#pragma unroll
+        for (int i = 0; i < 17; ++i)
+            d[i] = q[static_cast<uint32_t>(i) < last_dword ? static_cast<uint32_t>(i) : last_dword];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 17; ++i)
+            d[i] = 0u;
+    }
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
-        const uint32_t hi = (4u * (t + 1) < span) ? q[t + 1] : 0u;
-        uint32_t word = __builtin_amdgcn_perm(hi, lo, sel);
-        lo = hi;
+        uint32_t word = __builtin_amdgcn_perm(d[t + 1], d[t], sel);
         // Valid message bytes in this word: rem - 4t clamped to [0, 4].
         const int valid = static_cast<int>(rem) - 4 * t;
         if (valid <= 0) {

@@ -12,9 +12,10 @@
 //                      Throughput path (many small files).
 //   sha1_wave_kernel   one message per wavefront.  The 64 lanes expand and
 //                      K-bias the message schedules of 64 consecutive blocks in
-//                      parallel (state-independent work) into LDS; the serial
-//                      80-round chain then runs once per block reading its
-//                      schedule from LDS.  Latency path (few large files).
+//                      parallel (state-independent work) into their own
+//                      registers; the serial 80-round chain then hops from lane
+//                      to lane, one block per lane.  Latency path (few large
+//                      files).
 #include "sha1_device.hpp"
 #include "sha1_launch.hpp"
 #include "wave_util.hpp"
@@ -87,6 +88,8 @@ sha1_lanes_kernel(const uint8_t *__restrict__ base, const Sha1Task *__restrict__
             bool last = false;
             if (mode == 1) {
                 if (rem >= 64) {
+                    // Memory latency is covered by the other waves on the SIMD (the
+                    // kernel runs at eight waves per SIMD), not by prefetching.
                     load_block_be(p, w);
                     p += 64;
                     rem -= 64;
@@ -112,18 +115,35 @@ sha1_lanes_kernel(const uint8_t *__restrict__ base, const Sha1Task *__restrict__
 // One message per wavefront.
 // ---------------------------------------------------------------------------
 
-// LDS image of one superblock: the K-biased schedule words of up to 64 blocks,
-// stored as [quad q = t/4][block][4 words] so that a lane writes 16 contiguous
-// bytes next to its neighbours' (conflict-free ds_write_b128) and the chain
-// reads one broadcast 16-byte slot per four rounds.
+// A superblock is 64 consecutive 64-byte blocks of one message: lane j expands
+// block j's schedule (K already added) into 80 registers of its own.  The chain
+// state then visits the lanes in order: all lanes execute the 80 rounds, the lane
+// that currently holds the state does so on its own schedule registers, and one
+// DPP rotate per state word (wave_ror:1) hands the state to the next lane.  The
+// serial part of a block is therefore 400 round instructions + 5 adds + 5
+// rotates, with no memory or LDS access on the chain.
 constexpr int kSuper = 64;
-constexpr int kQuads = 20;
+constexpr uint32_t kDppWaveRor1 = 0x13C;
+
+__device__ __forceinline__ uint32_t rotate_to_next_lane(uint32_t v)
+{
+    return __builtin_amdgcn_update_dpp(v, v, kDppWaveRor1, 0xF, 0xF, false);
+}
+
+// Schedule words K + W[0..79] of the block whose 16 big-endian words are in w.
+__device__ __forceinline__ void expand_biased(uint32_t (&w)[16], uint32_t (&wk)[80])
+{
+#pragma unroll
+    for (int t = 0; t < 80; ++t) {
+        const uint32_t wt = (t < 16) ? w[t] : sha1_schedule(w, t);
+        wk[t] = wt + kSha1K[t / 20];
+    }
+}
 
 __global__ void __launch_bounds__(kWave)
 sha1_wave_kernel(const uint8_t *__restrict__ base, const Sha1Task *__restrict__ tasks,
                  uint32_t n_tasks, uint32_t *__restrict__ queue, uint8_t *__restrict__ digests)
 {
-    __shared__ uint4 wk[kQuads * kSuper];
     const uint32_t lane = lane_id();
 
     for (;;) {
@@ -136,65 +156,67 @@ sha1_wave_kernel(const uint8_t *__restrict__ base, const Sha1Task *__restrict__ 
         const uint64_t n_full = len >> 6;
         const uint32_t rem = static_cast<uint32_t>(len & 63u);
         const uint64_t n_blocks = n_full + (rem < 56 ? 1u : 2u);
+        const uint32_t shift = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(msg) & 3u);
 
+        // The state lives in one lane at a time, lane 0 first.
         uint32_t h[5];
 #pragma unroll
         for (int k = 0; k < 5; ++k)
             h[k] = kSha1Init[k];
 
+        // Raw dwords of this lane's block in the coming superblock, loaded one
+        // superblock ahead so the chain never waits for memory.
+        uint32_t raw[17];
+#pragma unroll
+        for (int k = 0; k < 17; ++k)
+            raw[k] = 0;
+        if (lane < n_full)
+            load_block_raw(msg + (static_cast<uint64_t>(lane) << 6), shift, raw);
+
+        uint32_t hops = 0;
         for (uint64_t blk0 = 0; blk0 < n_blocks; blk0 += kSuper) {
             const uint32_t nb =
                 static_cast<uint32_t>(n_blocks - blk0 < kSuper ? n_blocks - blk0 : kSuper);
 
-            // Phase 1: lane j expands block blk0+j.
-            if (lane < nb) {
+            // Phase 1: lane j expands block blk0+j (lanes past the end idle).
+            uint32_t wk[80];
+            {
                 const uint64_t b = blk0 + lane;
                 uint32_t w[16];
                 if (b < n_full)
-                    load_block_be(msg + (b << 6), w);
+                    raw_block_to_be(raw, shift, w);
                 else if (b == n_full)
                     load_tail_block_be(msg + (n_full << 6), rem, len, w);
                 else
                     make_length_block(len, w);
-#pragma unroll
-                for (int q = 0; q < kQuads; ++q) {
-                    uint32_t v[4];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const int t = 4 * q + k;
-                        const uint32_t wt = (t < 16) ? w[t] : sha1_schedule(w, t);
-                        v[k] = wt + kSha1K[t / 20];
-                    }
-                    wk[q * kSuper + lane] = make_uint4(v[0], v[1], v[2], v[3]);
-                }
+                expand_biased(w, wk);
+                __builtin_amdgcn_sched_barrier(0);
+                const uint64_t nxt = b + kSuper;
+                if (nxt < n_full)
+                    load_block_raw(msg + (nxt << 6), shift, raw);
             }
-            __syncthreads();
 
-            // Phase 2: the serial chain, one block after another.  Every lane runs it
-            // on the same broadcast words: a wave issues one instruction per ~4.5
-            // cycles whatever its EXEC mask, and a one-lane mask measured slower.
-            {
-                for (uint32_t b = 0; b < nb; ++b) {
-                    uint32_t a = h[0], bb = h[1], c = h[2], d = h[3], e = h[4];
+            // Phase 2: the chain hops through the lanes.
+            for (uint32_t b = 0; b < nb; ++b) {
+                uint32_t a = h[0], bb = h[1], c = h[2], d = h[3], e = h[4];
 #pragma unroll
-                    for (int q = 0; q < kQuads; ++q) {
-                        const uint4 v = wk[q * kSuper + b];
-                        const uint32_t x[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                        for (int k = 0; k < 4; ++k)
-                            sha1_round<true>(4 * q + k, a, bb, c, d, e, x[k]);
-                    }
-                    h[0] += a;
-                    h[1] += bb;
-                    h[2] += c;
-                    h[3] += d;
-                    h[4] += e;
-                }
+                for (int t = 0; t < 80; ++t)
+                    sha1_round<true>(t, a, bb, c, d, e, wk[t]);
+                h[0] = rotate_to_next_lane(h[0] + a);
+                h[1] = rotate_to_next_lane(h[1] + bb);
+                h[2] = rotate_to_next_lane(h[2] + c);
+                h[3] = rotate_to_next_lane(h[3] + d);
+                h[4] = rotate_to_next_lane(h[4] + e);
             }
-            __syncthreads();
+            hops += nb;
         }
-        // All lanes hold the same state and store the same bytes.
-        store_digest(digests + 20ull * task.out_index, h);
+        // The state ended in lane (hops mod 64); every lane stores the same bytes.
+        const uint32_t holder = hops & (kWave - 1);
+        uint32_t out[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k)
+            out[k] = __builtin_amdgcn_readlane(h[k], holder);
+        store_digest(digests + 20ull * task.out_index, out);
     }
 }
 
