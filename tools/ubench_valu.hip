@@ -50,19 +50,19 @@ static void run(const char *name, int instr_per_iter, int threads, int active, i
     uint64_t *d_cycles;
     uint32_t *d_sink;
     const int waves = blocks * threads / 64;
-    hipMalloc(&d_cycles, waves * sizeof(uint64_t));
-    hipMalloc(&d_sink, blocks * threads * sizeof(uint32_t));
+    (void)hipMalloc(&d_cycles, waves * sizeof(uint64_t));
+    (void)hipMalloc(&d_sink, blocks * threads * sizeof(uint32_t));
     for (int rep = 0; rep < 2; ++rep)
         hipLaunchKernelGGL(bench<MODE>, dim3(blocks), dim3(threads), 0, 0, d_cycles, d_sink, iters, active);
-    hipDeviceSynchronize();
+    (void)hipDeviceSynchronize();
     std::vector<uint64_t> h(waves);
-    hipMemcpy(h.data(), d_cycles, waves * sizeof(uint64_t), hipMemcpyDeviceToHost);
+    (void)hipMemcpy(h.data(), d_cycles, waves * sizeof(uint64_t), hipMemcpyDeviceToHost);
     double sum = 0;
     for (auto v : h) sum += double(v);
     printf("%-28s threads/block=%4d blocks=%4d active_lanes=%2d  cycles/instr/wave=%.3f\n", name, threads,
            blocks, active, sum / waves / iters / instr_per_iter);
-    hipFree(d_cycles);
-    hipFree(d_sink);
+    (void)hipFree(d_cycles);
+    (void)hipFree(d_sink);
 }
 
 int main()
