@@ -144,6 +144,20 @@ int snappy_mcdf_decode_and_hash(const uint8_t *in, uint64_t in_len,
                                 uint64_t *n_files, uint64_t *body_offset,
                                 uint8_t *out_payload, uint64_t out_cap, uint64_t *payload_len);
 
+/* The same import for several archives at once (the loop a bulk import would
+ * run over McdfManager.ImportMcdf, McdfManager.cs:68): one decode launch and one
+ * hash launch cover every archive, which is what fills the GPU -- an archive is
+ * only a few hundred 1 MiB chunks.  digests/statuses hold the Files entries of
+ * archive 0, then archive 1, ... (n_files[a] entries each; n_files_cap is their
+ * total capacity).  archive_status[a] is that archive's SNAPPY_* status; an
+ * archive that failed contributes no entries and does not disturb the others.
+ * body_offsets and payload_lens may be NULL. */
+int snappy_mcdf_decode_and_hash_batch(uint64_t n_archives, const uint8_t *const *ins,
+                                      const uint64_t *in_lens, uint8_t *digests,
+                                      uint8_t *statuses, uint64_t n_files_cap,
+                                      uint64_t *n_files, uint64_t *body_offsets,
+                                      uint64_t *payload_lens, int *archive_status);
+
 /* --------------------------------------------------------------- profiling */
 
 /* Kernel timing of the most recent compute call made by this thread, measured

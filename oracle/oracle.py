@@ -160,8 +160,9 @@ def lz4net_decode(stream, out_cap=None):
     if out_cap is None:
         st, out_cap = lz4net_decoded_size(stream)
         if st != OK:
-            # Still run the decoder: it reports errors in stream order.
-            out_cap = max(out_cap, 1 << 16)
+            # Still run the decoder (it reports errors in stream order) with room for
+            # whatever precedes the bad chunk: LZ4 expands at most 255x.
+            out_cap = min(255 * n + (1 << 16), 1 << 31)
     out = (ctypes.c_uint8 * max(out_cap, 1))()
     v = ctypes.c_uint64(0)
     st = lib().oracle_lz4net_decode(arr, n, out, out_cap, ctypes.byref(v))

@@ -9,5 +9,6 @@ from .mcdf import (  # noqa: F401
     lz4net_decode,
     lz4net_decoded_size,
     mcdf_decode_and_hash,
+    mcdf_decode_and_hash_batch,
     mcdf_parse_header,
 )

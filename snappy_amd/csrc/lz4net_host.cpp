@@ -97,24 +97,33 @@ void parse_lz4net_stream(const uint8_t *in, uint64_t in_len, Lz4netLayout &layou
     }
 }
 
-int decode_lz4net_on_device(SlotLease &lease, const uint8_t *in, uint64_t in_len,
-                            const Lz4netLayout &layout, DecodedOnDevice &out)
+int decode_streams_on_device(SlotLease &lease, std::vector<StreamJob> &jobs)
 {
     Slot &s = *lease.slot;
-    const uint64_t n_chunks = layout.chunks.size();
-    // Device arena: [stream | slack][payload].  The slack lets the decoder's
-    // input window read whole dwords past the last stream byte.
-    const uint64_t in_alloc = (in_len + 256 + 255) & ~uint64_t(255);
-    const uint64_t payload_off = in_alloc;
+    // Device arena: [stream 0 | slack][stream 1 | slack]...[payload 0][payload 1]...
+    // The slack lets the decoder's input window read whole dwords past a stream's
+    // last byte; every region starts on a 256-byte boundary.
+    uint64_t cursor = 0, n_chunks = 0;
+    for (StreamJob &j : jobs) {
+        j.in_off = cursor;
+        cursor += (j.in_len + 256 + 255) & ~uint64_t(255);
+        n_chunks += j.layout.chunks.size();
+    }
+    const uint64_t in_alloc = cursor;
+    for (StreamJob &j : jobs) {
+        j.out_off = cursor;
+        cursor += (j.layout.decoded_size + 255) & ~uint64_t(255);
+    }
     int st;
-    if ((st = s.d_data.ensure(static_cast<size_t>(payload_off + layout.decoded_size + 64))) !=
-        SNAPPY_OK)
+    if ((st = s.d_data.ensure(static_cast<size_t>(cursor + 64))) != SNAPPY_OK)
         return st;
-    uint8_t *d_in = static_cast<uint8_t *>(s.d_data.ptr);
-    out.d_payload = d_in + payload_off;
-    out.size = layout.decoded_size;
+    uint8_t *arena = static_cast<uint8_t *>(s.d_data.ptr);
+    for (StreamJob &j : jobs) {
+        j.d_payload = arena + j.out_off;
+        j.status = j.layout.stop_status;
+    }
     if (n_chunks == 0)
-        return layout.stop_status;
+        return SNAPPY_OK;
     if (n_chunks > 0xFFFFFFF0ull)
         return SNAPPY_E_INVALID_ARG;
 
@@ -126,9 +135,21 @@ int decode_lz4net_on_device(SlotLease &lease, const uint8_t *in, uint64_t in_len
     if ((st = s.h_stage.ensure(std::max(table_bytes, status_bytes))) != SNAPPY_OK) return st;
 
     hipStream_t stream = s.stream;
-    SNAPPY_HIP_TRY(hipMemsetAsync(d_in + in_len, 0, in_alloc - in_len, stream));
-    SNAPPY_HIP_TRY(hipMemcpyAsync(d_in, in, in_len, hipMemcpyHostToDevice, stream));
-    std::memcpy(s.h_stage.ptr, layout.chunks.data(), table_bytes);
+    Lz4Chunk *table = static_cast<Lz4Chunk *>(s.h_stage.ptr);
+    uint64_t k = 0;
+    for (StreamJob &j : jobs) {
+        const uint64_t region = (j.in_len + 256 + 255) & ~uint64_t(255);
+        SNAPPY_HIP_TRY(hipMemsetAsync(arena + j.in_off + j.in_len, 0, region - j.in_len, stream));
+        if (j.in_len)
+            SNAPPY_HIP_TRY(hipMemcpyAsync(arena + j.in_off, j.in, j.in_len, hipMemcpyHostToDevice,
+                                          stream));
+        for (const Lz4Chunk &c : j.layout.chunks) {
+            table[k] = c;
+            table[k].in_off += j.in_off;
+            table[k].out_off += j.out_off;
+            ++k;
+        }
+    }
     SNAPPY_HIP_TRY(hipMemcpyAsync(s.d_tasks.ptr, s.h_stage.ptr, table_bytes, hipMemcpyHostToDevice,
                                   stream));
     SNAPPY_HIP_TRY(hipMemsetAsync(s.d_misc.ptr, 0, 256, stream));
@@ -139,7 +160,7 @@ int decode_lz4net_on_device(SlotLease &lease, const uint8_t *in, uint64_t in_len
     // One wave per chunk in flight; four waves per workgroup.
     const int blocks = static_cast<int>(std::min<uint64_t>(
         (n_chunks + 3) / 4, static_cast<uint64_t>(lease.dev->n_cu) * 8u));
-    SNAPPY_HIP_TRY(launch_lz4_decode(d_in, in_alloc, out.d_payload,
+    SNAPPY_HIP_TRY(launch_lz4_decode(arena, in_alloc, arena,
                                      static_cast<const Lz4Chunk *>(s.d_tasks.ptr),
                                      static_cast<uint32_t>(n_chunks),
                                      static_cast<uint32_t *>(s.d_misc.ptr),
@@ -154,11 +175,30 @@ int decode_lz4net_on_device(SlotLease &lease, const uint8_t *in, uint64_t in_len
         if (hipEventElapsedTime(&ms, s.ev_prof[1][0], s.ev_prof[1][1]) == hipSuccess)
             profile_store(1, ms);
     }
+    // A malformed block comes before whatever ended the header walk after it.
     const uint32_t *status = static_cast<const uint32_t *>(s.h_stage.ptr);
-    for (uint64_t i = 0; i < n_chunks; ++i)
-        if (status[i] != 0)
-            return SNAPPY_E_LZ4_CORRUPT;
-    return layout.stop_status;
+    k = 0;
+    for (StreamJob &j : jobs) {
+        for (size_t c = 0; c < j.layout.chunks.size(); ++c, ++k)
+            if (status[k] != 0)
+                j.status = SNAPPY_E_LZ4_CORRUPT;
+    }
+    return SNAPPY_OK;
+}
+
+int decode_lz4net_on_device(SlotLease &lease, const uint8_t *in, uint64_t in_len,
+                            const Lz4netLayout &layout, DecodedOnDevice &out)
+{
+    std::vector<StreamJob> jobs(1);
+    jobs[0].in = in;
+    jobs[0].in_len = in_len;
+    jobs[0].layout = layout;
+    int st = decode_streams_on_device(lease, jobs);
+    if (st != SNAPPY_OK)
+        return st;
+    out.d_payload = jobs[0].d_payload;
+    out.size = layout.decoded_size;
+    return jobs[0].status;
 }
 
 }  // namespace snappy

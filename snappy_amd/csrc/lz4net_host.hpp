@@ -28,6 +28,24 @@ struct DecodedOnDevice {
     uint64_t size = 0;
 };
 
+// One lz4net stream of a batch: the caller fills in/in_len/layout, the decode
+// fills the rest.  status = SNAPPY_E_LZ4_CORRUPT when a block is malformed, else
+// layout.stop_status.
+struct StreamJob {
+    const uint8_t *in = nullptr;
+    uint64_t in_len = 0;
+    Lz4netLayout layout;
+    uint64_t in_off = 0;   // of the stream in the slot's device arena
+    uint64_t out_off = 0;  // of its payload in the arena
+    uint8_t *d_payload = nullptr;
+    int status = SNAPPY_OK;
+};
+
+// Uploads all streams and decodes all their chunks in one launch, so that a
+// batch of archives fills the GPU (a 1 MiB chunk is one wavefront's work).
+// Returns an infrastructure status; per-stream results are in jobs[i].status.
+int decode_streams_on_device(SlotLease &lease, std::vector<StreamJob> &jobs);
+
 // Uploads the stream, decodes every chunk of `layout` on the lease's device and
 // leaves the payload in HBM.  Returns SNAPPY_E_LZ4_CORRUPT when a block is
 // malformed, else layout.stop_status.

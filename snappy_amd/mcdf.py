@@ -32,7 +32,9 @@ def lz4net_decode(stream, out_cap=None) -> bytes:
         try:
             out_cap = lz4net_decoded_size(buf)
         except native.SnappyError:
-            out_cap = 1 << 16  # the decode call reports the error in stream order
+            # the decode call reports the error in stream order; leave room for
+            # whatever precedes the bad chunk (LZ4 expands at most 255x)
+            out_cap = min(255 * buf.size + (1 << 16), 1 << 31)
     out = np.zeros(max(out_cap, 1), dtype=np.uint8)
     v = ctypes.c_uint64(0)
     native.check(native.lib().snappy_lz4net_decode(buf.ctypes.data if buf.size else None, buf.size,
@@ -89,3 +91,38 @@ def mcdf_decode_and_hash(stream, want_payload: bool = False, n_files_cap: int = 
             "payload_len": plen.value,
             "payload": payload[: plen.value].tobytes() if want_payload else None,
         }
+
+
+def mcdf_decode_and_hash_batch(streams, n_files_cap: int = 4096):
+    """Several archives through one decode launch and one hash launch.
+    Returns a list of dicts (status, digests, statuses, body_offset, payload_len), one per archive."""
+    bufs = [_as_u8(s) for s in streams]
+    n = len(bufs)
+    lib = native.lib()
+    ptrs = (ctypes.c_void_p * max(n, 1))(*[b.ctypes.data if b.size else None for b in bufs])
+    lens = np.array([b.size for b in bufs], dtype=np.uint64)
+    while True:
+        digests = np.zeros((max(n_files_cap, 1), 20), dtype=np.uint8)
+        statuses = np.zeros(max(n_files_cap, 1), dtype=np.uint8)
+        n_files = np.zeros(max(n, 1), dtype=np.uint64)
+        body = np.zeros(max(n, 1), dtype=np.uint64)
+        plen = np.zeros(max(n, 1), dtype=np.uint64)
+        ast = np.zeros(max(n, 1), dtype=np.int32)
+        st = lib.snappy_mcdf_decode_and_hash_batch(n, ptrs, lens.ctypes.data, digests.ctypes.data,
+                                                   statuses.ctypes.data, n_files_cap,
+                                                   n_files.ctypes.data, body.ctypes.data,
+                                                   plen.ctypes.data, ast.ctypes.data)
+        if st == native.E_CAPACITY and int(n_files.sum()) > n_files_cap:
+            n_files_cap = int(n_files.sum())
+            continue
+        native.check(st, "snappy_mcdf_decode_and_hash_batch")
+        break
+    out = []
+    at = 0
+    for a in range(n):
+        k = int(n_files[a])
+        out.append({"status": int(ast[a]), "digests": digests[at: at + k].copy(),
+                    "statuses": statuses[at: at + k].copy(), "body_offset": int(body[a]),
+                    "payload_len": int(plen[a])})
+        at += k
+    return out

@@ -51,6 +51,7 @@ SYMBOLS = [
     ("snappy_lz4net_decode", _i, [_vp, _u64, _vp, _u64, _u64p]),
     ("snappy_mcdf_parse_header", _i, [_vp, _u64, _u64p, _u64p, _vp, _u64]),
     ("snappy_mcdf_decode_and_hash", _i, [_vp, _u64, _vp, _vp, _u64, _u64p, _u64p, _vp, _u64, _u64p]),
+    ("snappy_mcdf_decode_and_hash_batch", _i, [_u64, _vp, _vp, _vp, _vp, _u64, _vp, _vp, _vp, _vp]),
     ("snappy_profile_enable", None, [_i]),
     ("snappy_profile_last_ms", ctypes.c_float, [_i]),
 ]

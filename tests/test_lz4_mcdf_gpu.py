@@ -182,3 +182,32 @@ def test_mcdf_short_read_and_errors(snappy, oracle):
     with pytest.raises(snappy.native.SnappyError) as es:
         snappy.mcdf_decode_and_hash(stream[:-7])
     assert es.value.code == snappy.native.E_LZ4_TRUNCATED
+
+
+def test_mcdf_batch_matches_single_and_oracle(snappy, oracle):
+    """Several archives in one call: good ones, a truncated stream, a bad header, an empty stream."""
+    from snappy_amd.crypto import digests_to_hex
+
+    good = [_make_archive(oracle, 10 + 3 * k, 10 + k, chunk=1 << 18)[0] for k in range(4)]
+    bad_header = oracle.lz4net_encode(b"XCDF" + bytes(100), chunk_size=1 << 16)
+    streams = [good[0], good[1][:-9], bad_header, good[2], b"", good[3]]
+    res = snappy.mcdf_decode_and_hash_batch(streams, n_files_cap=3)   # forces the capacity retry
+    assert len(res) == len(streams)
+    for s, r in zip(streams, res):
+        try:
+            ref = oracle.mcdf_import(s)
+            want_status = 0
+        except oracle.McdfError as e:
+            ref, want_status = None, e.code
+        assert r["status"] == want_status
+        if ref is None:
+            assert len(r["statuses"]) == 0
+            continue
+        assert list(r["statuses"]) == ref["statuses"]
+        assert r["body_offset"] == ref["body_offset"] and r["payload_len"] == len(ref["payload"])
+        single = snappy.mcdf_decode_and_hash(s)
+        assert np.array_equal(single["digests"], r["digests"])
+        hx = digests_to_hex(r["digests"])
+        for (paths, _), st, h in zip(ref["data"]["Files"], ref["statuses"], hx):
+            if st == oracle.FILE_HASHED and paths:
+                assert h in ref["blobs"]
