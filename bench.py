@@ -246,6 +246,45 @@ def cpu_baseline(host_sample: np.ndarray, offsets, lengths):
     return res, out
 
 
+def dry_run(args, rank, world):
+    """The N-rank control flow of main() without a GPU: per-rank corpus, barrier, timed steps,
+    MAX of the times and SUM of the bytes over ranks, one JSON line from rank 0."""
+    import torch
+    import torch.distributed as dist
+
+    from oracle import oracle
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(0x534E4150 + rank)
+    lengths = make_sizes(args.workload if args.workload != "mcdf" else "folder", rng, 2e-3 * args.scale)
+    offsets = np.concatenate([[0], np.cumsum(lengths)[:-1]]).astype(np.uint64)
+    base = np.random.default_rng(rank).integers(0, 256, size=int(lengths.sum()) + 1, dtype=np.uint8)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        digests = oracle.sha1_batch_np(base, offsets, lengths)
+    elapsed = time.perf_counter() - t0
+    job_bytes = float(lengths.sum())
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        tot = torch.tensor([job_bytes], dtype=torch.float64)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        job_bytes = float(tot.item())
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "steps": args.steps, "scaling": "weak",
+                          "value": job_bytes * args.steps / elapsed / GB, "unit": "GB/s",
+                          "job_bytes": job_bytes, "files_rank0": int(len(lengths)),
+                          "digest0": digests[0].tobytes().hex()}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -256,6 +295,9 @@ def main():
     ap.add_argument("--archive-mib", type=float, default=128.0, help="mcdf workload: decoded MiB per archive")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink or grow the corpus")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-dry-run", action="store_true",
+                    help="no GPU: exercise the multi-rank plumbing with the CPU oracle standing in for the "
+                         "kernels on a tiny corpus (used by the gloo test; the numbers mean nothing)")
     ap.add_argument("--cpu-sample-gb", type=float, default=4.0)
     args = ap.parse_args()
 
@@ -265,7 +307,10 @@ def main():
 
     import torch
 
-    import snappy_amd
+    if args.cpu_dry_run:
+        return dry_run(args, rank, world)
+
+    import snappy_amd  # noqa: F401
     from snappy_amd import native
 
     if not torch.cuda.is_available():

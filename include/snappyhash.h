@@ -107,6 +107,13 @@ int snappy_sha1_batch_device(int device, const void *d_base, const uint64_t *off
                              const uint64_t *lengths, uint64_t n, uint8_t *digests,
                              void *stream);
 
+/* How snappy_sha1_batch / snappy_sha1_files split a batch over devices: files
+ * are independent, so shard k is the contiguous group cuts[k] .. cuts[k+1] of
+ * near-equal byte count (cuts has n_shards + 1 entries).  Host only; exposed so
+ * that a caller running one process per GPU can shard a file list the same way.
+ * No counterpart in the reference (its loops are sequential). */
+int snappy_plan_shards(const uint64_t *lengths, uint64_t n, uint32_t n_shards, uint64_t *cuts);
+
 /* ----------------------------------------------------- lz4net stream + MCDF */
 
 /* Walks the chunk headers of an lz4net LZ4Stream (what McdfManager.cs:73-79

@@ -82,3 +82,12 @@ def sha1_batch_device(device: int, d_base: int, offsets, lengths, stream: int = 
                                                        stream or None),
                  "snappy_sha1_batch_device")
     return out
+
+
+def plan_shards(lengths, n_shards: int) -> np.ndarray:
+    """Contiguous shards of near-equal byte count; returns n_shards + 1 cut indices."""
+    ln = np.ascontiguousarray(lengths, dtype=np.uint64)
+    cuts = np.zeros(n_shards + 1, dtype=np.uint64)
+    native.check(native.lib().snappy_plan_shards(ln.ctypes.data, ln.shape[0], n_shards,
+                                                 cuts.ctypes.data), "snappy_plan_shards")
+    return cuts

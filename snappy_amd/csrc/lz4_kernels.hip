@@ -71,6 +71,7 @@ __device__ __forceinline__ void copy_bytes(uint8_t *dst, const uint8_t *src, uin
 {
     uint32_t i = lane;
     // Four loads in flight per lane before the first store.
+#pragma clang loop vectorize(disable) unroll(disable)
     for (; i + 3u * kWave < n; i += 4u * kWave) {
         const uint8_t a = src[i], b = src[i + kWave], c = src[i + 2 * kWave], d = src[i + 3 * kWave];
         dst[i] = a;
@@ -78,18 +79,43 @@ __device__ __forceinline__ void copy_bytes(uint8_t *dst, const uint8_t *src, uin
         dst[i + 2 * kWave] = c;
         dst[i + 3 * kWave] = d;
     }
+#pragma clang loop vectorize(disable) unroll(disable)
     for (; i < n; i += kWave)
         dst[i] = src[i];
 }
 
-// Same for long runs, one dword per lane: the destination is brought to a dword
-// boundary, source dwords are read aligned and funnel-shifted (v_alignbyte_b32)
-// by the source's misalignment.
+// Same for long runs, 16 bytes per lane and four such loads in flight per lane
+// (4 KiB per wave per iteration), so the copy is bound by bandwidth rather than
+// by one memory round trip per 64 bytes.  The destination is brought to a
+// 16-byte boundary; the source is read as dword-aligned 16-byte pieces plus one
+// more dword and funnel-shifted (v_alignbyte_b32) by its misalignment.
+struct Piece {
+    uint32_t v[4];
+    uint32_t extra;
+};
+
+__device__ __forceinline__ Piece load_piece(const uint32_t *s, uint32_t vec, uint32_t shift)
+{
+    Piece p;
+    __builtin_memcpy(p.v, s + 4u * vec, 16);  // dword-aligned 16-byte load
+    p.extra = shift ? s[4u * vec + 4u] : 0u;  // holds source bytes only when misaligned
+    return p;
+}
+
+__device__ __forceinline__ void store_piece(uint8_t *dst, uint32_t vec, const Piece &p, uint32_t shift)
+{
+    uint4 o;
+    o.x = __builtin_amdgcn_alignbyte(p.v[1], p.v[0], shift);
+    o.y = __builtin_amdgcn_alignbyte(p.v[2], p.v[1], shift);
+    o.z = __builtin_amdgcn_alignbyte(p.v[3], p.v[2], shift);
+    o.w = __builtin_amdgcn_alignbyte(p.extra, p.v[3], shift);
+    reinterpret_cast<uint4 *>(dst)[vec] = o;
+}
+
 __device__ __forceinline__ void copy_long(uint8_t *dst, const uint8_t *src, uint32_t n,
                                           uint32_t lane)
 {
-    // Bring dst to a dword boundary.
-    const uint32_t head = (4u - static_cast<uint32_t>(reinterpret_cast<uintptr_t>(dst) & 3u)) & 3u;
+    const uint32_t head = (16u - static_cast<uint32_t>(reinterpret_cast<uintptr_t>(dst) & 15u)) & 15u;
     if (head) {
         if (lane < head)
             dst[lane] = src[lane];
@@ -99,24 +125,24 @@ __device__ __forceinline__ void copy_long(uint8_t *dst, const uint8_t *src, uint
     }
     const uint32_t shift = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(src) & 3u);
     const uint32_t *s = reinterpret_cast<const uint32_t *>(src - shift);
-    uint32_t *d = reinterpret_cast<uint32_t *>(dst);
-    const uint32_t n_dwords = n >> 2;
-    // dst dword k = bytes [4k+shift, 4k+shift+4) of s: funnel of s[k] and s[k+1].
-    // s[k+1] is read only when it holds source bytes (shift != 0).
+    const uint32_t n_vec = n >> 4;
     uint32_t k = lane;
-    for (; k + kWave < n_dwords; k += 2u * kWave) {
-        const uint32_t a0 = s[k], b0 = s[k + kWave];
-        const uint32_t a1 = shift ? s[k + 1] : 0u, b1 = shift ? s[k + kWave + 1] : 0u;
-        d[k] = __builtin_amdgcn_alignbyte(a1, a0, shift);
-        d[k + kWave] = __builtin_amdgcn_alignbyte(b1, b0, shift);
+#pragma clang loop vectorize(disable) unroll(disable)
+    for (; k + 3u * kWave < n_vec; k += 4u * kWave) {
+        const Piece a = load_piece(s, k, shift);
+        const Piece b = load_piece(s, k + kWave, shift);
+        const Piece c = load_piece(s, k + 2u * kWave, shift);
+        const Piece d = load_piece(s, k + 3u * kWave, shift);
+        store_piece(dst, k, a, shift);
+        store_piece(dst, k + kWave, b, shift);
+        store_piece(dst, k + 2u * kWave, c, shift);
+        store_piece(dst, k + 3u * kWave, d, shift);
     }
-    for (; k < n_dwords; k += kWave) {
-        const uint32_t a0 = s[k];
-        const uint32_t a1 = shift ? s[k + 1] : 0u;
-        d[k] = __builtin_amdgcn_alignbyte(a1, a0, shift);
-    }
-    const uint32_t done = n_dwords << 2;
-    if (lane < (n & 3u))
+#pragma clang loop vectorize(disable) unroll(disable)
+    for (; k < n_vec; k += kWave)
+        store_piece(dst, k, load_piece(s, k, shift), shift);
+    const uint32_t done = n_vec << 4;
+    if (lane < (n & 15u))
         dst[done + lane] = src[done + lane];
 }
 
@@ -153,6 +179,7 @@ __device__ __forceinline__ void copy_periodic(uint8_t *dst, uint32_t period, uin
         uint32_t r = lane % period;
         const uint32_t step = kWave % period;
         uint32_t i = lane;
+#pragma clang loop vectorize(disable) unroll(disable)
         for (; i + 3u * kWave < head; i += 4u * kWave) {
             uint32_t r1 = r + step;
             r1 -= (r1 >= period) ? period : 0u;
@@ -168,6 +195,7 @@ __device__ __forceinline__ void copy_periodic(uint8_t *dst, uint32_t period, uin
             r = r3 + step;
             r -= (r >= period) ? period : 0u;
         }
+#pragma clang loop vectorize(disable) unroll(disable)
         for (; i < head; i += kWave) {
             dst[i] = pat[r];
             r += step;

@@ -225,6 +225,28 @@ int hash_ranges_on_device(int device, const HostRange *ranges, uint64_t first, u
     return run_sha1_plan(lease, d_base, plan, digests + 20 * first, nullptr);
 }
 
+}  // namespace
+
+// Contiguous groups of near-equal byte count: cuts[k]..cuts[k+1] is shard k.
+void plan_shards(const uint64_t *lengths, uint64_t n, uint32_t n_shards, uint64_t *cuts)
+{
+    uint64_t total = 0;
+    for (uint64_t i = 0; i < n; ++i)
+        total += lengths[i];
+    for (uint32_t k = 0; k <= n_shards; ++k)
+        cuts[k] = n;
+    cuts[0] = 0;
+    uint64_t acc = 0;
+    uint32_t k = 1;
+    for (uint64_t i = 0; i < n && k < n_shards; ++i) {
+        acc += lengths[i];
+        while (k < n_shards && acc * n_shards >= total * k)
+            cuts[k++] = i + 1;
+    }
+}
+
+namespace {
+
 // Files are independent, so a batch shards across devices with no exchange:
 // contiguous groups of near-equal byte count, one host thread per device.
 int hash_ranges(const std::vector<HostRange> &ranges, uint8_t *digests)
@@ -249,15 +271,11 @@ int hash_ranges(const std::vector<HostRange> &ranges, uint8_t *digests)
     if (shards <= 1)
         return hash_ranges_on_device(pick_device(), ranges.data(), 0, n, digests);
 
+    std::vector<uint64_t> lens(n);
+    for (uint64_t i = 0; i < n; ++i)
+        lens[i] = ranges[i].len;
     std::vector<uint64_t> cut(static_cast<size_t>(shards) + 1, n);
-    cut[0] = 0;
-    uint64_t acc = 0;
-    int k = 1;
-    for (uint64_t i = 0; i < n && k < shards; ++i) {
-        acc += ranges[i].len;
-        if (acc * static_cast<uint64_t>(shards) >= total * static_cast<uint64_t>(k))
-            cut[static_cast<size_t>(k++)] = i + 1;
-    }
+    plan_shards(lens.data(), n, static_cast<uint32_t>(shards), cut.data());
     std::vector<int> status(static_cast<size_t>(shards), SNAPPY_OK);
     std::vector<std::thread> workers;
     for (int d = 0; d < shards; ++d) {
@@ -280,6 +298,15 @@ int hash_ranges(const std::vector<HostRange> &ranges, uint8_t *digests)
 }  // namespace snappy
 
 using namespace snappy;
+
+extern "C" int snappy_plan_shards(const uint64_t *lengths, uint64_t n, uint32_t n_shards,
+                                  uint64_t *cuts)
+{
+    if ((n && !lengths) || !cuts || n_shards == 0)
+        return SNAPPY_E_INVALID_ARG;
+    plan_shards(lengths, n, n_shards, cuts);
+    return SNAPPY_OK;
+}
 
 extern "C" int snappy_sha1(const uint8_t *data, uint64_t len, uint8_t out20[20])
 {

@@ -20,6 +20,10 @@ struct Sha1Plan {
 void build_sha1_plan(const uint64_t *offsets, const uint64_t *lengths, uint64_t n, int n_cu,
                      Sha1Plan &plan);
 
+// Splits n files into n_shards contiguous groups of near-equal byte count
+// (cuts has n_shards + 1 entries).
+void plan_shards(const uint64_t *lengths, uint64_t n, uint32_t n_shards, uint64_t *cuts);
+
 // Uploads the plan, runs the kernels on the lease's device and returns the
 // digests (20 bytes per message, in the caller's message order) in host memory.
 int run_sha1_plan(SlotLease &lease, const uint8_t *d_base, const Sha1Plan &plan,

@@ -1,0 +1,95 @@
+"""The N > 1 path without GPUs: two gloo ranks run bench.py's control flow (barrier, MAX of
+times, SUM of bytes, one JSON line), and a file list is sharded the way the library shards a
+batch over devices, each rank hashing its shard (the CPU oracle stands in for the kernels)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+import helpers as H
+
+
+def test_bench_two_ranks_gloo(tmp_path):
+    env = dict(os.environ)
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29731", os.path.join(H.ROOT, "bench.py"),
+           "--gpus", "2", "--steps", "2", "--warmup", "0", "--cpu-dry-run"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env, cwd=H.ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout          # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["dry_run"] is True
+    # both ranks' bytes were summed: each corpus is ~16 MB at this scale
+    single = subprocess.run([sys.executable, os.path.join(H.ROOT, "bench.py"), "--steps", "1", "--warmup", "0",
+                             "--cpu-dry-run"], capture_output=True, text=True, timeout=240, cwd=H.ROOT)
+    assert single.returncode == 0, single.stderr[-2000:]
+    one = json.loads([ln for ln in single.stdout.splitlines() if ln.startswith("{")][0])
+    assert one["n_gpus"] == 1
+    assert 1.5 * one["job_bytes"] < d["job_bytes"] < 2.5 * one["job_bytes"]
+    assert one["digest0"] == d["digest0"]         # rank 0 hashes the same corpus either way
+
+
+def _worker(rank, world, port, lengths, seed, ret):
+    import torch.distributed as dist
+
+    from oracle import oracle
+    from snappy_amd.crypto import plan_shards
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lengths = np.asarray(lengths, dtype=np.uint64)
+    offsets = np.concatenate([[0], np.cumsum(lengths)[:-1]]).astype(np.uint64)
+    base = np.random.default_rng(seed).integers(0, 256, size=int(lengths.sum()) + 1, dtype=np.uint8)
+    cuts = plan_shards(lengths, world)            # the library's own split, one shard per rank
+    lo, hi = int(cuts[rank]), int(cuts[rank + 1])
+    mine = oracle.sha1_batch_np(base, offsets[lo:hi], lengths[lo:hi])
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (lo, hi, mine.tobytes()))   # host-side concatenation, no reduction
+    if rank == 0:
+        ret.put(gathered)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_file_list_two_ranks(oracle, snappy):
+    import torch.multiprocessing as mp
+
+    rng = np.random.default_rng(4)
+    lengths = np.concatenate([H.mixed_sizes(rng, 60, 1000, 400_000), [0, 1, 3_000_000]])
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, 29741, lengths.tolist(), 99, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    gathered = ret.get(timeout=200)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # coverage: the shards tile the list exactly once, in order
+    assert gathered[0][0] == 0 and gathered[0][1] == gathered[1][0] and gathered[1][1] == len(lengths)
+    merged = b"".join(g[2] for g in gathered)
+    offsets = np.concatenate([[0], np.cumsum(lengths)[:-1]]).astype(np.uint64)
+    base = np.random.default_rng(99).integers(0, 256, size=int(lengths.sum()) + 1, dtype=np.uint8)
+    want = oracle.sha1_batch_np(base, offsets, lengths.astype(np.uint64))
+    assert merged == want.tobytes()
+    # balance: neither shard holds more than ~the largest file above half the bytes
+    b0 = int(lengths[: gathered[0][1]].sum())
+    assert abs(b0 - lengths.sum() / 2) <= lengths.max()
+
+
+def test_plan_shards_properties(snappy):
+    from snappy_amd.crypto import plan_shards
+
+    rng = np.random.default_rng(8)
+    for n, k in [(0, 3), (1, 4), (5, 5), (1000, 8), (37, 2)]:
+        ln = rng.integers(0, 1 << 20, size=n).astype(np.uint64)
+        cuts = plan_shards(ln, k)
+        assert cuts[0] == 0 and cuts[-1] == n and np.all(np.diff(cuts.astype(np.int64)) >= 0)
+        if n >= 100:
+            per = np.array([ln[int(cuts[i]): int(cuts[i + 1])].sum() for i in range(k)], dtype=np.float64)
+            assert per.max() <= ln.sum() / k + ln.max()
