@@ -299,6 +299,8 @@ def main():
                     help="no GPU: exercise the multi-rank plumbing with the CPU oracle standing in for the "
                          "kernels on a tiny corpus (used by the gloo test; the numbers mean nothing)")
     ap.add_argument("--cpu-sample-gb", type=float, default=4.0)
+    ap.add_argument("--e2e", action="store_true",
+                    help="also time the host-pointer entry point (PCIe copy inside the call) on the same corpus")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -428,6 +430,22 @@ def main():
             "chain_ns_per_block": k_ms * 1e6 / max_blocks,
         },
     }
+
+    if args.e2e:
+        # PCIe-inclusive: the same corpus in ordinary host memory through snappy_sha1_batch.
+        host_all = buf[:total_bytes].cpu().numpy()
+        d2 = np.zeros((n, 20), dtype=np.uint8)
+        times = []
+        for _ in range(2):
+            t0 = time.perf_counter()
+            native.check(lib.snappy_sha1_batch(host_all.ctypes.data, offsets.ctypes.data,
+                                               lengths.ctypes.data, n, d2.ctypes.data), "snappy_sha1_batch")
+            times.append(time.perf_counter() - t0)
+        out["e2e_host_pointers"] = {"value": total_bytes / min(times) / GB, "unit": "GB/s",
+                                    "ms": min(times) * 1e3, "kernel_ms": lib.snappy_profile_last_ms(0),
+                                    "note": "pageable host memory -> HBM -> kernels -> digests, one call",
+                                    "digests_match_resident_run": bool(np.array_equal(d2, digests))}
+        del host_all
 
     if not args.no_cpu_baseline:
         # Bounded sample: the first files of rank 0's corpus up to the sample size.

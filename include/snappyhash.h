@@ -165,6 +165,28 @@ int snappy_mcdf_decode_and_hash_batch(uint64_t n_archives, const uint8_t *const 
                                       uint64_t *n_files, uint64_t *body_offsets,
                                       uint64_t *payload_lens, int *archive_status);
 
+/* ------------------------------------------------ headless callers (files) */
+
+/* The hash-and-store loop with its file system side: for every path that names
+ * an existing file, read it whole (File.ReadAllBytes, SnapshotManager.cs:317),
+ * hash it (all files in one GPU batch), write hex[41*i..] = its 40 uppercase hex
+ * characters + NUL, and -- when files_dir is not NULL -- store the bytes as
+ * files_dir/<HASH>.dat unless that file exists (SnapshotManager.cs:453-475; the
+ * migrator's variant is Snappy/Data/SnapshotMigrator.cs:62-86).
+ * status[i]: 0 = hashed, 1 = no such file (the loops `continue`, hex[41*i] = NUL). */
+int snappy_store_files(const char *const *paths, uint64_t n, const char *files_dir,
+                       char *hex, uint8_t *status);
+
+/* McdfManager.ImportMcdf without UI and plugin IPC (McdfManager.cs:68-156):
+ * reads the archive, decodes and hashes it on the GPU, and writes the snapshot
+ * folder working_dir/<Description or MCDF_Import_yyyyMMddHHmmss> (replaced when
+ * it exists): _files/<HASH>.dat for every file body, snapshot.json (Snappy/
+ * Models/SnapshotInfo.cs:6-14), glamourer_history.json, customize_history.json
+ * (SnapshotManager.cs:672-695; the importable Customize+ template is left
+ * empty).  snapshot_dir_out (may be NULL) receives the folder's path. */
+int snappy_mcdf_import_to_dir(const char *mcdf_path, const char *working_dir,
+                              char *snapshot_dir_out, uint64_t out_cap);
+
 /* --------------------------------------------------------------- profiling */
 
 /* Kernel timing of the most recent compute call made by this thread, measured

@@ -12,3 +12,4 @@ from .mcdf import (  # noqa: F401
     mcdf_decode_and_hash_batch,
     mcdf_parse_header,
 )
+from .snapshot import import_mcdf, store_files  # noqa: F401,E402

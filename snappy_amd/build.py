@@ -23,6 +23,7 @@ SOURCES = [
     "lz4net_host.cpp",
     "mcdf_host.cpp",
     "mcdf_api.cpp",
+    "host_mirror.cpp",
 ]
 
 

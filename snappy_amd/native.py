@@ -53,6 +53,8 @@ SYMBOLS = [
     ("snappy_mcdf_parse_header", _i, [_vp, _u64, _u64p, _u64p, _vp, _u64]),
     ("snappy_mcdf_decode_and_hash", _i, [_vp, _u64, _vp, _vp, _u64, _u64p, _u64p, _vp, _u64, _u64p]),
     ("snappy_mcdf_decode_and_hash_batch", _i, [_u64, _vp, _vp, _vp, _vp, _u64, _vp, _vp, _vp, _vp]),
+    ("snappy_store_files", _i, [_vp, _u64, ctypes.c_char_p, _vp, _vp]),
+    ("snappy_mcdf_import_to_dir", _i, [ctypes.c_char_p, ctypes.c_char_p, _vp, _u64]),
     ("snappy_profile_enable", None, [_i]),
     ("snappy_profile_last_ms", ctypes.c_float, [_i]),
 ]
