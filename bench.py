@@ -211,6 +211,63 @@ def run_mcdf(args, rank, world, local_rank, dist):
     }
 
 
+def extra_workloads(args, lib, native, torch, device, local_rank):
+    """The other single-GPU configurations, measured briefly after the headline run so that one
+    bench line also carries the small-file (throughput) and MCDF (LZ4 decode) kernels' rooflines."""
+    res = {}
+    # 10^6 files of 4-32 KB: the one-message-per-lane kernel.
+    rng = np.random.default_rng(0x534E4151)
+    lengths = make_sizes("small", rng, 1.0)
+    offsets = np.concatenate([[0], np.cumsum(lengths)[:-1]]).astype(np.uint64)
+    total = int(lengths.sum())
+    algo = int(padded_blocks(lengths).sum()) * 64
+    buf = fill_random(torch, total, device, seed=99)
+    n = len(lengths)
+    stream = torch.cuda.current_stream().cuda_stream
+    d_off = torch.from_numpy(offsets.astype(np.int64)).to(device)
+    d_len = torch.from_numpy(lengths.astype(np.int64)).to(device)
+    d_dig = torch.zeros(n * 20, dtype=torch.uint8, device=device)
+    k_ms, t_ms = [], []
+    for it in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        native.check(lib.snappy_sha1_batch_resident(local_rank, buf.data_ptr(), d_off.data_ptr(),
+                                                    d_len.data_ptr(), n, d_dig.data_ptr(), stream),
+                     "snappy_sha1_batch_resident")
+        if it:
+            t_ms.append((time.perf_counter() - t0) * 1e3)
+            k_ms.append(lib.snappy_profile_last_ms(0))
+    digests = d_dig.cpu().numpy().reshape(n, 20)
+    import hashlib
+    ok = all(hashlib.sha1(buf[int(offsets[i]): int(offsets[i] + lengths[i])].cpu().numpy().tobytes()).digest()
+             == digests[i].tobytes() for i in (0, 1, n // 2, n - 1))
+    km = float(np.mean(k_ms))
+    res["small_files"] = {
+        "workload": "10^6 files of 4-32 KB, SHA-1, data + (offset,len) table + digests resident in HBM",
+        "value": total / (np.mean(t_ms) * 1e-3) / GB, "unit": "GB/s", "ms_per_step": float(np.mean(t_ms)),
+        "roofline": {"bound": "hbm", "achieved": algo / (km * 1e-3) / GB, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": algo / (km * 1e-3) / GB / HBM_PEAK_GBS,
+                     "kernel": "sha1_lanes_kernel", "kernel_ms": km, "algorithmic_bytes_per_launch": algo,
+                     "valu_ceiling_GBps": 4200.0,
+                     "note": "integer-VALU bound: 613 instructions per 64-byte block; 4.2 TB/s is the "
+                             "measured register-only compression ceiling (tools/ubench_sha1.hip)"},
+        "digests_match_hashlib_sample": bool(ok)}
+    del buf
+    torch.cuda.empty_cache()
+    # MCDF import: lz4net decode + slice + hash, 8 archives of 256 MiB in one call.
+    class A:
+        pass
+    a = A()
+    a.archives, a.archive_mib, a.steps, a.warmup = 8, 256.0, 2, 1
+    m = run_mcdf(a, 0, 1, local_rank, None)
+    res["mcdf_import"] = {"workload": m["config"]["workload"], "value": m["value"], "unit": "GB/s",
+                          "ms_per_step": m["ms_per_step"], "roofline": m["roofline"],
+                          "compressed_bytes": m["config"]["compressed_bytes_per_gpu"],
+                          "decoded_bytes": m["config"]["decoded_bytes_per_gpu"],
+                          "digests_match_hashlib_sample": m["digests_match_hashlib_sample"]}
+    return res
+
+
 def cpu_baseline(host_sample: np.ndarray, offsets, lengths):
     """The reference loop (read -> SHA-1 -> uppercase hex, sequential, one thread:
     Snappy/Core/SnapshotManager.cs:312-324) timed with the CPU oracle on a bounded sample."""
@@ -299,6 +356,8 @@ def main():
                     help="no GPU: exercise the multi-rank plumbing with the CPU oracle standing in for the "
                          "kernels on a tiny corpus (used by the gloo test; the numbers mean nothing)")
     ap.add_argument("--cpu-sample-gb", type=float, default=4.0)
+    ap.add_argument("--no-extra", action="store_true",
+                    help="skip the brief small-file and MCDF measurements appended to the default run")
     ap.add_argument("--e2e", action="store_true",
                     help="also time the host-pointer entry point (PCIe copy inside the call) on the same corpus")
     args = ap.parse_args()
@@ -351,10 +410,21 @@ def main():
     digests = np.zeros((n, 20), dtype=np.uint8)
     stream = torch.cuda.current_stream().cuda_stream
 
+    resident = args.workload == "small"   # the (offset, length) table is part of the resident input
+    if resident:
+        d_off = torch.from_numpy(offsets.astype(np.int64)).to(device)
+        d_len = torch.from_numpy(lengths.astype(np.int64)).to(device)
+        d_dig = torch.zeros(n * 20, dtype=torch.uint8, device=device)
+
     def step():
-        native.check(lib.snappy_sha1_batch_device(local_rank, buf.data_ptr(), offsets.ctypes.data,
-                                                  lengths.ctypes.data, n, digests.ctypes.data,
-                                                  stream), "snappy_sha1_batch_device")
+        if resident:
+            native.check(lib.snappy_sha1_batch_resident(local_rank, buf.data_ptr(), d_off.data_ptr(),
+                                                        d_len.data_ptr(), n, d_dig.data_ptr(), stream),
+                         "snappy_sha1_batch_resident")
+        else:
+            native.check(lib.snappy_sha1_batch_device(local_rank, buf.data_ptr(), offsets.ctypes.data,
+                                                      lengths.ctypes.data, n, digests.ctypes.data,
+                                                      stream), "snappy_sha1_batch_device")
 
     def barrier():
         torch.cuda.synchronize()
@@ -371,6 +441,8 @@ def main():
         kernel_ms.append(lib.snappy_profile_last_ms(0))
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    if resident:
+        digests[:] = d_dig.cpu().numpy().reshape(n, 20)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -407,7 +479,7 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": {"blobs": "8 GiB corpus of 4-64 MiB blobs per GPU, SHA-1, inputs resident in HBM",
-                         "small": "10^6 files of 4-32 KB per GPU, SHA-1, inputs resident in HBM",
+                         "small": "10^6 files of 4-32 KB per GPU, SHA-1, data + (offset,len) table + digests resident in HBM",
                          "folder": "one snapshot folder (160 files, ~200 MB), SHA-1, inputs resident in HBM"}[args.workload],
             "files_per_gpu": n,
             "bytes_per_gpu": total_bytes,
@@ -430,6 +502,9 @@ def main():
             "chain_ns_per_block": k_ms * 1e6 / max_blocks,
         },
     }
+
+    if world == 1 and args.workload == "blobs" and args.scale == 1.0 and not args.no_extra:
+        out["other_workloads"] = extra_workloads(args, lib, native, torch, device, local_rank)
 
     if args.e2e:
         # PCIe-inclusive: the same corpus in ordinary host memory through snappy_sha1_batch.

@@ -107,6 +107,15 @@ int snappy_sha1_batch_device(int device, const void *d_base, const uint64_t *off
                              const uint64_t *lengths, uint64_t n, uint8_t *digests,
                              void *stream);
 
+/* The same with everything resident: d_offsets, d_lengths (n entries each) and
+ * d_digests (20*n bytes) are device memory too, so nothing but the launch
+ * crosses PCIe; the size ordering and the split between kernels are computed on
+ * the device.  Returns after the digests are in d_digests.  No counterpart in
+ * the reference; for callers that keep asset tables on the GPU. */
+int snappy_sha1_batch_resident(int device, const void *d_base, const uint64_t *d_offsets,
+                               const uint64_t *d_lengths, uint64_t n, uint8_t *d_digests,
+                               void *stream);
+
 /* How snappy_sha1_batch / snappy_sha1_files split a batch over devices: files
  * are independent, so shard k is the contiguous group cuts[k] .. cuts[k+1] of
  * near-equal byte count (cuts has n_shards + 1 entries).  Host only; exposed so

@@ -17,6 +17,7 @@ LIB = os.path.join(HERE, "libsnappyhash.so")
 
 SOURCES = [
     "sha1_kernels.hip",
+    "sha1_plan.hip",
     "lz4_kernels.hip",
     "runtime.cpp",
     "sha1_api.cpp",

@@ -91,3 +91,11 @@ def plan_shards(lengths, n_shards: int) -> np.ndarray:
     native.check(native.lib().snappy_plan_shards(ln.ctypes.data, ln.shape[0], n_shards,
                                                  cuts.ctypes.data), "snappy_plan_shards")
     return cuts
+
+
+def sha1_batch_resident(device: int, d_base: int, d_offsets: int, d_lengths: int, n: int,
+                        d_digests: int, stream: int = 0) -> None:
+    """Everything in HBM: device addresses of the data, the two uint64 tables and the 20*n digest bytes."""
+    native.check(native.lib().snappy_sha1_batch_resident(device, d_base, d_offsets, d_lengths, n,
+                                                         d_digests, stream or None),
+                 "snappy_sha1_batch_resident")

@@ -75,10 +75,9 @@ int import_batch(SlotLease &lease, std::vector<StreamJob> &jobs, std::vector<Arc
         }
     }
     if (!owner.empty()) {
-        Sha1Plan plan;
-        build_sha1_plan(offsets.data(), lengths.data(), owner.size(), lease.dev->n_cu, plan);
         std::vector<uint8_t> packed(owner.size() * 20);
-        st = run_sha1_plan(lease, arena, plan, packed.data(), nullptr);
+        st = run_sha1_tables(lease, arena, offsets.data(), lengths.data(), owner.size(),
+                             packed.data(), nullptr);
         if (st != SNAPPY_OK)
             return st;
         for (size_t k = 0; k < owner.size(); ++k)

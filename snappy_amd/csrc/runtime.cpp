@@ -38,6 +38,7 @@ void destroy_slot(Slot &s)
 {
     s.d_data.release();
     s.d_tasks.release();
+    s.d_tables.release();
     s.d_out.release();
     s.d_misc.release();
     s.h_stage.release();

@@ -51,6 +51,7 @@ struct Slot {
     hipEvent_t ev_prof[kProfileKernels][2] = {};
     Buffer d_data;     // device arena for host-pointer calls
     Buffer d_tasks;    // Sha1Task[] / chunk tables
+    Buffer d_tables;   // (offset, length) tables of a batch
     Buffer d_out;      // digests / statuses
     Buffer d_misc;     // queue counters, error words
     Buffer h_stage;    // pinned host staging (tasks up, digests down)

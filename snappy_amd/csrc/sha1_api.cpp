@@ -1,4 +1,4 @@
-// SHA-1 entry points of libsnappyhash: batch planning, staging, dispatch.
+// SHA-1 entry points of libsnappyhash: staging, device-side planning, dispatch.
 //
 // Mirrors /root/reference/Snappy/Utils/Crypto.cs:8-22 (GetHash, ToHashedString)
 // and the three loops that call it (Snappy/Core/SnapshotManager.cs:312-324,
@@ -27,146 +27,95 @@ constexpr double kNsPerBlockLane = 1300.0;
 // waves (64 messages share an instruction stream at ~2.5 cycles/instruction).
 constexpr double kSimdNsPerBlockLane = 650.0 * 2.5 / 64.0 / 2.4;
 
-inline uint64_t padded_blocks(uint64_t len) { return (len + 8) / 64 + 1; }
-
 long env_long(const char *name, long fallback)
 {
     const char *v = std::getenv(name);
     return (v && *v) ? std::atol(v) : fallback;
 }
 
-// Descending size order without a comparison sort: 8 buckets per octave of the
-// padded block count (order inside a bucket does not matter to the schedule).
-inline uint32_t size_bucket(uint64_t blocks)
-{
-    const int e = 63 - __builtin_clzll(blocks | 1);
-    const uint32_t mant = (e >= 3) ? static_cast<uint32_t>((blocks >> (e - 3)) & 7)
-                                   : static_cast<uint32_t>((blocks << (3 - e)) & 7);
-    return static_cast<uint32_t>(e) * 8u + mant;
-}
-
 }  // namespace
 
-void build_sha1_plan(const uint64_t *offsets, const uint64_t *lengths, uint64_t n, int n_cu,
-                     Sha1Plan &plan)
-{
-    constexpr uint32_t kBuckets = 64 * 8;
-    std::vector<uint32_t> count(kBuckets + 1, 0);
-    uint64_t total_blocks = 0, max_blocks = 0;
-    for (uint64_t i = 0; i < n; ++i) {
-        const uint64_t b = padded_blocks(lengths[i]);
-        total_blocks += b;
-        max_blocks = std::max(max_blocks, b);
-        ++count[kBuckets - 1 - size_bucket(b)];  // reversed: big buckets first
-    }
-    uint32_t run = 0;
-    for (uint32_t k = 0; k <= kBuckets; ++k) {
-        const uint32_t c = count[k];
-        count[k] = run;
-        run += c;
-    }
-    plan.tasks.resize(n);
-    for (uint64_t i = 0; i < n; ++i) {
-        const uint64_t b = padded_blocks(lengths[i]);
-        Sha1Task &t = plan.tasks[count[kBuckets - 1 - size_bucket(b)]++];
-        t.offset = offsets[i];
-        t.len = lengths[i];
-        t.out_index = static_cast<uint32_t>(i);
-        t.reserved = 0;
-    }
-    plan.total_blocks = total_blocks;
-
-    // Split.  The batch cannot finish before its largest message has run its
-    // serial chain on the faster (wave) path, nor before the lane path has issued
-    // all its blocks.  A message goes to the wave path when the lane path would
-    // keep it past ~80 % of that bound; when there are no more messages than
-    // SIMDs every message gets a wave (and a SIMD) of its own.
-    const uint64_t n_simd = 4ull * static_cast<uint64_t>(n_cu);
-    const double t_star = std::max(static_cast<double>(max_blocks) * kNsPerBlockWave,
-                                   static_cast<double>(total_blocks) * kSimdNsPerBlockLane /
-                                       static_cast<double>(n_simd));
-    double thr_blocks = (n <= n_simd) ? 0.0 : 0.8 * t_star / kNsPerBlockLane;
-    const long forced = env_long("SNAPPY_WAVE_MIN_BLOCKS", -1);  // tuning/testing override
-    if (forced >= 0)
-        thr_blocks = static_cast<double>(forced);
-    const uint64_t max_wave_tasks = 2 * n_simd;
-    uint32_t n_wave = 0;
-    while (n_wave < n && n_wave < max_wave_tasks &&
-           static_cast<double>(padded_blocks(plan.tasks[n_wave].len)) > thr_blocks)
-        ++n_wave;
-    plan.n_wave = n_wave;
-}
-
-int run_sha1_plan(SlotLease &lease, const uint8_t *d_base, const Sha1Plan &plan,
-                  uint8_t *digests_host, hipStream_t user_stream)
+int enqueue_sha1_resident(SlotLease &lease, const uint8_t *d_base, const uint64_t *d_offsets,
+                          const uint64_t *d_lengths, uint64_t n, uint8_t *d_digests,
+                          hipStream_t stream)
 {
     Slot &s = *lease.slot;
-    const uint64_t n = plan.tasks.size();
     if (n == 0)
         return SNAPPY_OK;
-    hipStream_t stream = user_stream ? user_stream : s.stream;
-
-    const size_t task_bytes = n * sizeof(Sha1Task);
-    const size_t digest_bytes = n * 20;
+    if (n >= 0xFFFFFFF0ull)
+        return SNAPPY_E_INVALID_ARG;
     int st;
-    if ((st = s.d_tasks.ensure(task_bytes)) != SNAPPY_OK) return st;
-    if ((st = s.d_out.ensure(digest_bytes)) != SNAPPY_OK) return st;
-    if ((st = s.d_misc.ensure(256)) != SNAPPY_OK) return st;
-    if ((st = s.h_stage.ensure(std::max(task_bytes, digest_bytes))) != SNAPPY_OK) return st;
-
-    std::memcpy(s.h_stage.ptr, plan.tasks.data(), task_bytes);
-    SNAPPY_HIP_TRY(hipMemcpyAsync(s.d_tasks.ptr, s.h_stage.ptr, task_bytes, hipMemcpyHostToDevice,
-                                  stream));
-    SNAPPY_HIP_TRY(hipMemsetAsync(s.d_misc.ptr, 0, 256, stream));
-
-    const uint32_t n_wave = plan.n_wave;
-    const uint32_t n_all = static_cast<uint32_t>(n);
-    uint32_t *q_wave = static_cast<uint32_t *>(s.d_misc.ptr);
-    uint32_t *q_lane = q_wave + 32;  // separate 128-byte line
-    const Sha1Task *d_tasks = static_cast<const Sha1Task *>(s.d_tasks.ptr);
-    uint8_t *d_digests = static_cast<uint8_t *>(s.d_out.ptr);
+    if ((st = s.d_tasks.ensure(n * sizeof(Sha1Task))) != SNAPPY_OK) return st;
+    if ((st = s.d_misc.ensure(sizeof(Sha1PlanState))) != SNAPPY_OK) return st;
+    Sha1PlanState *d_state = static_cast<Sha1PlanState *>(s.d_misc.ptr);
+    Sha1Task *d_tasks = static_cast<Sha1Task *>(s.d_tasks.ptr);
+    const uint32_t n32 = static_cast<uint32_t>(n);
+    const uint32_t n_simd = 4u * static_cast<uint32_t>(lease.dev->n_cu);
 
     const bool prof = profiling_enabled();
     if (prof)
         SNAPPY_HIP_TRY(hipEventRecord(s.ev_prof[0][0], stream));
+    SNAPPY_HIP_TRY(launch_sha1_plan(d_offsets, d_lengths, n32, d_state, d_tasks, n_simd,
+                                    kNsPerBlockWave, kNsPerBlockLane, kSimdNsPerBlockLane,
+                                    env_long("SNAPPY_WAVE_MIN_BLOCKS", -1), stream));
 
-    const int wave_groups =
-        static_cast<int>(std::min<uint64_t>(n_wave, static_cast<uint64_t>(lease.dev->n_cu) * 8u));
-    const uint32_t n_lane = n_all - n_wave;
+    // The split is known only on the device: both kernels are launched, sized for
+    // the most each could get; waves that find their queue empty leave at once.
+    const int wave_groups = static_cast<int>(std::min<uint64_t>(n, 2ull * n_simd));
     const long blocks_per_cu = std::max(1L, env_long("SNAPPY_LANE_BLOCKS_PER_CU", 8));
-    const int lane_blocks = static_cast<int>(std::min<uint64_t>(
-        (static_cast<uint64_t>(n_lane) + 255) / 256,
-        static_cast<uint64_t>(lease.dev->n_cu) * static_cast<uint64_t>(blocks_per_cu)));
-
-    if (n_wave > 0 && n_lane > 0) {
-        // Both kernels run side by side: the wave kernel on the side stream.
-        SNAPPY_HIP_TRY(hipEventRecord(s.ev_fork, stream));
-        SNAPPY_HIP_TRY(hipStreamWaitEvent(s.side_stream, s.ev_fork, 0));
-        SNAPPY_HIP_TRY(launch_sha1_wave(d_base, d_tasks, n_wave, q_wave, d_digests, wave_groups,
-                                        s.side_stream));
-        SNAPPY_HIP_TRY(launch_sha1_lanes(d_base, d_tasks, n_wave, n_all, q_lane, d_digests,
-                                         lane_blocks, stream));
-        SNAPPY_HIP_TRY(hipEventRecord(s.ev_join, s.side_stream));
-        SNAPPY_HIP_TRY(hipStreamWaitEvent(stream, s.ev_join, 0));
-    } else if (n_wave > 0) {
-        SNAPPY_HIP_TRY(launch_sha1_wave(d_base, d_tasks, n_wave, q_wave, d_digests, wave_groups,
-                                        stream));
-    } else {
-        SNAPPY_HIP_TRY(launch_sha1_lanes(d_base, d_tasks, 0, n_all, q_lane, d_digests, lane_blocks,
-                                         stream));
-    }
+    const int lane_blocks = static_cast<int>(
+        std::min<uint64_t>((n + 255) / 256, static_cast<uint64_t>(lease.dev->n_cu) *
+                                                static_cast<uint64_t>(blocks_per_cu)));
+    // Side by side: the wave kernel on the side stream.
+    SNAPPY_HIP_TRY(hipEventRecord(s.ev_fork, stream));
+    SNAPPY_HIP_TRY(hipStreamWaitEvent(s.side_stream, s.ev_fork, 0));
+    SNAPPY_HIP_TRY(
+        launch_sha1_wave(d_base, d_tasks, d_state, d_digests, wave_groups, s.side_stream));
+    SNAPPY_HIP_TRY(
+        launch_sha1_lanes(d_base, d_tasks, n32, d_state, d_digests, lane_blocks, stream));
+    SNAPPY_HIP_TRY(hipEventRecord(s.ev_join, s.side_stream));
+    SNAPPY_HIP_TRY(hipStreamWaitEvent(stream, s.ev_join, 0));
     if (prof)
         SNAPPY_HIP_TRY(hipEventRecord(s.ev_prof[0][1], stream));
+    return SNAPPY_OK;
+}
 
-    SNAPPY_HIP_TRY(hipMemcpyAsync(s.h_stage.ptr, d_digests, digest_bytes, hipMemcpyDeviceToHost,
-                                  stream));
+void finish_sha1_profile(SlotLease &lease)
+{
+    if (!profiling_enabled())
+        return;
+    float ms = -1.f;
+    if (hipEventElapsedTime(&ms, lease.slot->ev_prof[0][0], lease.slot->ev_prof[0][1]) ==
+        hipSuccess)
+        profile_store(0, ms);
+    else
+        (void)hipGetLastError();
+}
+
+int run_sha1_tables(SlotLease &lease, const uint8_t *d_base, const uint64_t *offsets,
+                    const uint64_t *lengths, uint64_t n, uint8_t *digests_host,
+                    hipStream_t user_stream)
+{
+    Slot &s = *lease.slot;
+    if (n == 0)
+        return SNAPPY_OK;
+    hipStream_t stream = user_stream ? user_stream : s.stream;
+    const size_t table_bytes = n * sizeof(uint64_t);
+    int st;
+    if ((st = s.d_tables.ensure(2 * table_bytes)) != SNAPPY_OK) return st;
+    if ((st = s.d_out.ensure(n * 20)) != SNAPPY_OK) return st;
+    uint64_t *d_off = static_cast<uint64_t *>(s.d_tables.ptr);
+    uint64_t *d_len = d_off + n;
+    SNAPPY_HIP_TRY(hipMemcpyAsync(d_off, offsets, table_bytes, hipMemcpyHostToDevice, stream));
+    SNAPPY_HIP_TRY(hipMemcpyAsync(d_len, lengths, table_bytes, hipMemcpyHostToDevice, stream));
+    uint8_t *d_digests = static_cast<uint8_t *>(s.d_out.ptr);
+    st = enqueue_sha1_resident(lease, d_base, d_off, d_len, n, d_digests, stream);
+    if (st != SNAPPY_OK)
+        return st;
+    SNAPPY_HIP_TRY(
+        hipMemcpyAsync(digests_host, d_digests, n * 20, hipMemcpyDeviceToHost, stream));
     SNAPPY_HIP_TRY(hipStreamSynchronize(stream));
-    std::memcpy(digests_host, s.h_stage.ptr, digest_bytes);
-    if (prof) {
-        float ms = -1.f;
-        if (hipEventElapsedTime(&ms, s.ev_prof[0][0], s.ev_prof[0][1]) == hipSuccess)
-            profile_store(0, ms);
-    }
+    finish_sha1_profile(lease);
     return SNAPPY_OK;
 }
 
@@ -220,9 +169,8 @@ int hash_ranges_on_device(int device, const HostRange *ranges, uint64_t first, u
     for (const Copy &c : copies)
         SNAPPY_HIP_TRY(hipMemcpyAsync(d_base + c.dst, c.src, c.len, hipMemcpyHostToDevice,
                                       s.stream));
-    Sha1Plan plan;
-    build_sha1_plan(dev_off.data(), lens.data(), n, lease.dev->n_cu, plan);
-    return run_sha1_plan(lease, d_base, plan, digests + 20 * first, nullptr);
+    return run_sha1_tables(lease, d_base, dev_off.data(), lens.data(), n, digests + 20 * first,
+                           nullptr);
 }
 
 }  // namespace
@@ -380,16 +328,38 @@ extern "C" int snappy_sha1_batch_device(int device, const void *d_base, const ui
         return SNAPPY_E_INVALID_ARG;
     if (n == 0)
         return SNAPPY_OK;
-    for (uint64_t i = 0; i < n; ++i)
-        if (lengths[i] && !d_base)
-            return SNAPPY_E_INVALID_ARG;
+    if (!d_base)
+        for (uint64_t i = 0; i < n; ++i)
+            if (lengths[i])
+                return SNAPPY_E_INVALID_ARG;
     SlotLease lease;
     int st = lease.acquire(device);
     if (st != SNAPPY_OK)
         return st;
     profile_reset();
-    Sha1Plan plan;
-    build_sha1_plan(offsets, lengths, n, lease.dev->n_cu, plan);
-    return run_sha1_plan(lease, static_cast<const uint8_t *>(d_base), plan, digests,
-                         static_cast<hipStream_t>(stream));
+    return run_sha1_tables(lease, static_cast<const uint8_t *>(d_base), offsets, lengths, n,
+                           digests, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int snappy_sha1_batch_resident(int device, const void *d_base,
+                                          const uint64_t *d_offsets, const uint64_t *d_lengths,
+                                          uint64_t n, uint8_t *d_digests, void *stream)
+{
+    if (n && (!d_offsets || !d_lengths || !d_digests))
+        return SNAPPY_E_INVALID_ARG;
+    if (n == 0)
+        return SNAPPY_OK;
+    SlotLease lease;
+    int st = lease.acquire(device);
+    if (st != SNAPPY_OK)
+        return st;
+    profile_reset();
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : lease.slot->stream;
+    st = enqueue_sha1_resident(lease, static_cast<const uint8_t *>(d_base), d_offsets, d_lengths,
+                               n, d_digests, s);
+    if (st != SNAPPY_OK)
+        return st;
+    SNAPPY_HIP_TRY(hipStreamSynchronize(s));
+    finish_sha1_profile(lease);
+    return SNAPPY_OK;
 }

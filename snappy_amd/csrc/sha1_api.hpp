@@ -9,24 +9,25 @@
 
 namespace snappy {
 
-struct Sha1Plan {
-    std::vector<Sha1Task> tasks;  // descending size; [0, n_wave) go to the wave kernel
-    uint32_t n_wave = 0;
-    uint64_t total_blocks = 0;  // padded 64-byte blocks over all messages
-};
+// Plans and launches the SHA-1 kernels for n messages whose (offset, length)
+// tables and data are all in device memory; digests (20 bytes per message, in
+// the caller's message order) are written to d_digests.  Enqueues only.
+int enqueue_sha1_resident(SlotLease &lease, const uint8_t *d_base, const uint64_t *d_offsets,
+                          const uint64_t *d_lengths, uint64_t n, uint8_t *d_digests,
+                          hipStream_t stream);
 
-// Orders the messages by size and splits them between the two kernels.
-// offsets are relative to the device base pointer the plan will run against.
-void build_sha1_plan(const uint64_t *offsets, const uint64_t *lengths, uint64_t n, int n_cu,
-                     Sha1Plan &plan);
+// After the stream has been synchronised: stores the kernels' event time for
+// snappy_profile_last_ms(0).
+void finish_sha1_profile(SlotLease &lease);
+
+// Same for host tables and host digests: uploads the tables, runs the kernels on
+// the lease's device, downloads the digests and waits.
+int run_sha1_tables(SlotLease &lease, const uint8_t *d_base, const uint64_t *offsets,
+                    const uint64_t *lengths, uint64_t n, uint8_t *digests_host,
+                    hipStream_t user_stream);
 
 // Splits n files into n_shards contiguous groups of near-equal byte count
 // (cuts has n_shards + 1 entries).
 void plan_shards(const uint64_t *lengths, uint64_t n, uint32_t n_shards, uint64_t *cuts);
-
-// Uploads the plan, runs the kernels on the lease's device and returns the
-// digests (20 bytes per message, in the caller's message order) in host memory.
-int run_sha1_plan(SlotLease &lease, const uint8_t *d_base, const Sha1Plan &plan,
-                  uint8_t *digests_host, hipStream_t user_stream);
 
 }  // namespace snappy

@@ -34,10 +34,11 @@ __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & (kWave - 1)
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 sha1_lanes_kernel(const uint8_t *__restrict__ base, const Sha1Task *__restrict__ tasks,
-                  uint32_t first, uint32_t end, uint32_t *__restrict__ queue,
-                  uint8_t *__restrict__ digests)
+                  uint32_t end, Sha1PlanState *__restrict__ state, uint8_t *__restrict__ digests)
 {
     const uint32_t lane = lane_id();
+    const uint32_t first = __builtin_amdgcn_readfirstlane(state->n_wave);
+    uint32_t *queue = &state->queue_lane;
     uint32_t h[5] = {0, 0, 0, 0, 0};
     const uint8_t *p = nullptr;
     uint64_t rem = 0, total = 0;
@@ -142,9 +143,11 @@ __device__ __forceinline__ void expand_biased(uint32_t (&w)[16], uint32_t (&wk)[
 
 __global__ void __launch_bounds__(kWave)
 sha1_wave_kernel(const uint8_t *__restrict__ base, const Sha1Task *__restrict__ tasks,
-                 uint32_t n_tasks, uint32_t *__restrict__ queue, uint8_t *__restrict__ digests)
+                 Sha1PlanState *__restrict__ state, uint8_t *__restrict__ digests)
 {
     const uint32_t lane = lane_id();
+    const uint32_t n_tasks = __builtin_amdgcn_readfirstlane(state->n_wave);
+    uint32_t *queue = &state->queue_wave;
 
     for (;;) {
         const uint32_t i = wave_claim(queue, 1u, lane);
@@ -222,24 +225,25 @@ sha1_wave_kernel(const uint8_t *__restrict__ base, const Sha1Task *__restrict__ 
 
 }  // namespace
 
-hipError_t launch_sha1_lanes(const uint8_t *d_base, const Sha1Task *d_tasks, uint32_t first,
-                             uint32_t end, uint32_t *d_queue, uint8_t *d_digests, int blocks,
+hipError_t launch_sha1_lanes(const uint8_t *d_base, const Sha1Task *d_tasks, uint32_t n,
+                             Sha1PlanState *d_state, uint8_t *d_digests, int blocks,
                              hipStream_t stream)
 {
-    if (end <= first || blocks <= 0)
+    if (n == 0 || blocks <= 0)
         return hipSuccess;
-    hipLaunchKernelGGL(sha1_lanes_kernel, dim3(blocks), dim3(256), 0, stream, d_base, d_tasks,
-                       first, end, d_queue, d_digests);
+    hipLaunchKernelGGL(sha1_lanes_kernel, dim3(blocks), dim3(256), 0, stream, d_base, d_tasks, n,
+                       d_state, d_digests);
     return hipGetLastError();
 }
 
-hipError_t launch_sha1_wave(const uint8_t *d_base, const Sha1Task *d_tasks, uint32_t n_tasks,
-                            uint32_t *d_queue, uint8_t *d_digests, int waves, hipStream_t stream)
+hipError_t launch_sha1_wave(const uint8_t *d_base, const Sha1Task *d_tasks,
+                            Sha1PlanState *d_state, uint8_t *d_digests, int waves,
+                            hipStream_t stream)
 {
-    if (n_tasks == 0 || waves <= 0)
+    if (waves <= 0)
         return hipSuccess;
     hipLaunchKernelGGL(sha1_wave_kernel, dim3(waves), dim3(kWave), 0, stream, d_base, d_tasks,
-                       n_tasks, d_queue, d_digests);
+                       d_state, d_digests);
     return hipGetLastError();
 }
 

@@ -175,3 +175,30 @@ def test_concurrent_callers(snappy, oracle):
     for t in threads:
         t.join()
     assert not errors
+
+
+def test_fully_resident_batch(snappy, oracle):
+    """Tables and digests in HBM as well: planned and hashed without host tables."""
+    import torch
+
+    from snappy_amd.crypto import sha1_batch_resident
+
+    rng = np.random.default_rng(41)
+    host = rng.integers(0, 256, size=24 << 20, dtype=np.uint8)
+    dev = torch.from_numpy(host).cuda()
+    for n, hi in ((1, 5000), (700, 30_000), (5000, 3000), (40, 2_000_000)):
+        lengths = rng.integers(0, hi, size=n).astype(np.int64)
+        offsets = rng.integers(0, host.size - hi, size=n).astype(np.int64)
+        d_off = torch.from_numpy(offsets).cuda()
+        d_len = torch.from_numpy(lengths).cuda()
+        d_dig = torch.zeros(n * 20, dtype=torch.uint8, device="cuda")
+        for forced in (None, "0", "1000000000"):
+            if forced is None:
+                os.environ.pop("SNAPPY_WAVE_MIN_BLOCKS", None)
+            else:
+                os.environ["SNAPPY_WAVE_MIN_BLOCKS"] = forced
+            d_dig.zero_()
+            sha1_batch_resident(0, dev.data_ptr(), d_off.data_ptr(), d_len.data_ptr(), n, d_dig.data_ptr())
+            got = d_dig.cpu().numpy().reshape(n, 20)
+            want = oracle.sha1_batch_np(host, offsets.astype(np.uint64), lengths.astype(np.uint64))
+            assert np.array_equal(got, want), (n, hi, forced)
