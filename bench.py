@@ -56,6 +56,21 @@ def make_sizes(workload: str, rng: np.random.Generator, scale: float):
         s = np.concatenate([tex, mdl])
         s = s * (200e6 * scale / s.sum())
         return np.maximum(s.astype(np.uint64), 1)
+    if workload == "corpus":      # mixed asset corpus: 70 % of the bytes .tex-like, 30 % .mdl-like
+        target = 100e9 * scale
+        tex, mdl = [], []
+        t = m = 0.0
+        while t < 0.7 * target:
+            s = float(np.exp(rng.uniform(np.log(256 << 10), np.log(22 << 20))))
+            tex.append(s)
+            t += s
+        while m < 0.3 * target:
+            s = float(np.exp(rng.uniform(np.log(64 << 10), np.log(6 << 20))))
+            mdl.append(s)
+            m += s
+        sizes = np.array(tex + mdl)
+        rng.shuffle(sizes)
+        return sizes.astype(np.uint64)
     raise SystemExit(f"unknown workload {workload}")
 
 
@@ -342,12 +357,25 @@ def dry_run(args, rank, world):
         dist.destroy_process_group()
 
 
+def last_plan(lib):
+    """How the planner cut the last batch: files per execution path and its expected time."""
+    import ctypes
+
+    ends = (ctypes.c_uint32 * 4)()
+    ms = ctypes.c_double(0.0)
+    if lib.snappy_sha1_last_plan(ends, ctypes.byref(ms)) != 0:
+        return None
+    e = [0] + list(ends)
+    names = ("64_lanes_per_file", "16_lanes_per_file", "4_lanes_per_file", "1_lane_per_file")
+    return {"files": {names[k]: e[k + 1] - e[k] for k in range(4)}, "planned_ms": ms.value}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="blobs", choices=["blobs", "small", "folder", "mcdf"])
+    ap.add_argument("--workload", default="blobs", choices=["blobs", "small", "folder", "corpus", "mcdf"])
     ap.add_argument("--archives", type=int, default=8, help="mcdf workload: archives per GPU")
     ap.add_argument("--archive-mib", type=float, default=128.0, help="mcdf workload: decoded MiB per archive")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink or grow the corpus")
@@ -480,7 +508,9 @@ def main():
         "config": {
             "workload": {"blobs": "8 GiB corpus of 4-64 MiB blobs per GPU, SHA-1, inputs resident in HBM",
                          "small": "10^6 files of 4-32 KB per GPU, SHA-1, data + (offset,len) table + digests resident in HBM",
-                         "folder": "one snapshot folder (160 files, ~200 MB), SHA-1, inputs resident in HBM"}[args.workload],
+                         "folder": "one snapshot folder (160 files, ~200 MB), SHA-1, inputs resident in HBM",
+                         "corpus": "mixed asset corpus (70 pct .tex-like 256 KB-22 MB, 30 pct .mdl-like 64 KB-6 MB), "
+                                   + f"{100 * args.scale:.1f} GB per GPU, SHA-1, inputs resident in HBM"}[args.workload],
             "files_per_gpu": n,
             "bytes_per_gpu": total_bytes,
             "largest_file_bytes": int(lengths.max()),
@@ -493,8 +523,9 @@ def main():
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": None,
-            "kernel": "sha1_wave_kernel + sha1_lanes_kernel (run side by side)",
+            "kernel": "sha1_hop_kernel",
             "kernel_ms": k_ms,
+            "plan": last_plan(lib),
             "algorithmic_bytes_per_launch": algo_bytes,
             # SHA-1 is serial inside a file: a batch cannot finish before its largest
             # file has run its chain, whatever the bandwidth.

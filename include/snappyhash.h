@@ -206,6 +206,15 @@ int snappy_mcdf_import_to_dir(const char *mcdf_path, const char *working_dir,
 void snappy_profile_enable(int on);
 float snappy_profile_last_ms(int kernel);
 
+/* How the most recent SHA-1 batch of this thread was cut into execution paths
+ * (recorded only while profiling is on).  path_end[k] is the end, in the
+ * batch's size-sorted order, of path k's range: 64, 16, 4 and 1 lanes of a
+ * wavefront per file; path_end[3] is the number of files.  planned_ms is the
+ * finishing time the planner's cost model expected.  Returns
+ * SNAPPY_E_INVALID_ARG when nothing was recorded.  No counterpart in the
+ * reference. */
+int snappy_sha1_last_plan(uint32_t path_end[4], double *planned_ms);
+
 #ifdef __cplusplus
 }
 #endif

@@ -24,9 +24,6 @@ thread_local float t_profile_ms[kProfileKernels] = {-1.f, -1.f};
 int create_slot(Slot &s)
 {
     SNAPPY_HIP_TRY(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
-    SNAPPY_HIP_TRY(hipStreamCreateWithFlags(&s.side_stream, hipStreamNonBlocking));
-    SNAPPY_HIP_TRY(hipEventCreateWithFlags(&s.ev_fork, hipEventDisableTiming));
-    SNAPPY_HIP_TRY(hipEventCreateWithFlags(&s.ev_join, hipEventDisableTiming));
     for (int k = 0; k < kProfileKernels; ++k)
         for (int j = 0; j < 2; ++j)
             SNAPPY_HIP_TRY(hipEventCreate(&s.ev_prof[k][j]));
@@ -46,14 +43,8 @@ void destroy_slot(Slot &s)
         for (int j = 0; j < 2; ++j)
             if (s.ev_prof[k][j])
                 (void)hipEventDestroy(s.ev_prof[k][j]);
-    if (s.ev_fork)
-        (void)hipEventDestroy(s.ev_fork);
-    if (s.ev_join)
-        (void)hipEventDestroy(s.ev_join);
     if (s.stream)
         (void)hipStreamDestroy(s.stream);
-    if (s.side_stream)
-        (void)hipStreamDestroy(s.side_stream);
 }
 
 // Caller holds g_init_mu.

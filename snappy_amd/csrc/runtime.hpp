@@ -46,8 +46,6 @@ constexpr int kProfileKernels = 2;  // 0 = SHA-1, 1 = LZ4 decode
 // Everything one in-flight call needs on one device.
 struct Slot {
     hipStream_t stream = nullptr;      // main stream of the call
-    hipStream_t side_stream = nullptr; // second stream for kernels that may overlap
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev_prof[kProfileKernels][2] = {};
     Buffer d_data;     // device arena for host-pointer calls
     Buffer d_tasks;    // Sha1Task[] / chunk tables

@@ -8,6 +8,7 @@
 #include "sha1_api.hpp"
 
 #include <algorithm>
+#include <cstddef>
 #include <cstdlib>
 #include <cstring>
 #include <thread>
@@ -16,16 +17,15 @@ namespace snappy {
 
 namespace {
 
-// Measured cost model, used only to split a batch between the two kernels:
-// nanoseconds one message spends per 64-byte block when its wavefront has a
-// SIMD to itself (both paths issue one instruction per ~4.2 cycles; the wave
-// path has 412 instructions per block on the chain, the lane path ~650 plus
-// what its 63 neighbours' tails cost).
-constexpr double kNsPerBlockWave = 714.0;
-constexpr double kNsPerBlockLane = 1300.0;
-// SIMD time one block costs on the lane path when a SIMD is saturated with
-// waves (64 messages share an instruction stream at ~2.5 cycles/instruction).
-constexpr double kSimdNsPerBlockLane = 650.0 * 2.5 / 64.0 / 2.4;
+// Measured cost model, used only to cut a batch into the kernel's paths (groups
+// of 64 / 16 / 4 / 1 lanes per message).  chain: nanoseconds a message spends
+// per 64-byte block when its wavefront has a SIMD to itself (one instruction
+// issues per ~4.2 cycles; 412 instructions per block on the chain plus the
+// schedule expansion shared by the group; the clock falls from ~2.4 GHz to
+// ~1.7 GHz as more lanes do real work).  simd: SIMD time a block costs.
+constexpr double kChainNs[kSha1Paths] = {723.0, 799.0, 985.0, 1667.0};
+constexpr double kSimdNs[kSha1Paths] = {723.0, 199.7, 61.6, 26.0};
+constexpr double kSlowPathMargin = 0.6;
 
 long env_long(const char *name, long fallback)
 {
@@ -52,38 +52,52 @@ int enqueue_sha1_resident(SlotLease &lease, const uint8_t *d_base, const uint64_
     const uint32_t n32 = static_cast<uint32_t>(n);
     const uint32_t n_simd = 4u * static_cast<uint32_t>(lease.dev->n_cu);
 
+    Sha1CostModel model;
+    for (int k = 0; k < kSha1Paths; ++k) {
+        model.chain_ns[k] = kChainNs[k];
+        model.simd_ns[k] = kSimdNs[k];
+    }
+    model.n_simd = n_simd;
+    model.slow_path_margin = kSlowPathMargin;
+    // SNAPPY_SHA1_FORCE_PATH = 0..3 sends every message down one path (tests, tuning).
+    model.forced_path = static_cast<int>(env_long("SNAPPY_SHA1_FORCE_PATH", -1));
+    if (model.forced_path >= kSha1Paths)
+        model.forced_path = -1;
+    model.forced_waves = static_cast<int>(env_long("SNAPPY_SHA1_WAVES_PER_SIMD", 0));
+
     const bool prof = profiling_enabled();
     if (prof)
         SNAPPY_HIP_TRY(hipEventRecord(s.ev_prof[0][0], stream));
-    SNAPPY_HIP_TRY(launch_sha1_plan(d_offsets, d_lengths, n32, d_state, d_tasks, n_simd,
-                                    kNsPerBlockWave, kNsPerBlockLane, kSimdNsPerBlockLane,
-                                    env_long("SNAPPY_WAVE_MIN_BLOCKS", -1), stream));
-
-    // The split is known only on the device: both kernels are launched, sized for
-    // the most each could get; waves that find their queue empty leave at once.
-    const int wave_groups = static_cast<int>(std::min<uint64_t>(n, 2ull * n_simd));
-    const long blocks_per_cu = std::max(1L, env_long("SNAPPY_LANE_BLOCKS_PER_CU", 8));
-    const int lane_blocks = static_cast<int>(
-        std::min<uint64_t>((n + 255) / 256, static_cast<uint64_t>(lease.dev->n_cu) *
-                                                static_cast<uint64_t>(blocks_per_cu)));
-    // Side by side: the wave kernel on the side stream.
-    SNAPPY_HIP_TRY(hipEventRecord(s.ev_fork, stream));
-    SNAPPY_HIP_TRY(hipStreamWaitEvent(s.side_stream, s.ev_fork, 0));
-    SNAPPY_HIP_TRY(
-        launch_sha1_wave(d_base, d_tasks, d_state, d_digests, wave_groups, s.side_stream));
-    SNAPPY_HIP_TRY(
-        launch_sha1_lanes(d_base, d_tasks, n32, d_state, d_digests, lane_blocks, stream));
-    SNAPPY_HIP_TRY(hipEventRecord(s.ev_join, s.side_stream));
-    SNAPPY_HIP_TRY(hipStreamWaitEvent(stream, s.ev_join, 0));
+    SNAPPY_HIP_TRY(launch_sha1_plan(d_offsets, d_lengths, n32, d_state, d_tasks, model, stream));
+    SNAPPY_HIP_TRY(launch_sha1_hop(d_base, d_tasks, d_state, d_digests, n32, n_simd, stream));
     if (prof)
         SNAPPY_HIP_TRY(hipEventRecord(s.ev_prof[0][1], stream));
     return SNAPPY_OK;
 }
 
+namespace {
+thread_local bool t_plan_valid = false;
+thread_local uint32_t t_plan_end[kSha1Paths];
+thread_local double t_plan_ms = 0.0;
+}  // namespace
+
 void finish_sha1_profile(SlotLease &lease)
 {
+    t_plan_valid = false;
     if (!profiling_enabled())
         return;
+    // Called after the stream has been synchronised: the planner's header is final.
+    Sha1PlanState head;
+    const size_t head_bytes = offsetof(Sha1PlanState, reserved1);
+    if (lease.slot->d_misc.ptr &&
+        hipMemcpy(&head, lease.slot->d_misc.ptr, head_bytes, hipMemcpyDeviceToHost) == hipSuccess) {
+        for (int k = 0; k < kSha1Paths; ++k)
+            t_plan_end[k] = head.path_end[k];
+        t_plan_ms = head.planned_ns * 1e-6;
+        t_plan_valid = true;
+    } else {
+        (void)hipGetLastError();
+    }
     float ms = -1.f;
     if (hipEventElapsedTime(&ms, lease.slot->ev_prof[0][0], lease.slot->ev_prof[0][1]) ==
         hipSuccess)
@@ -361,5 +375,16 @@ extern "C" int snappy_sha1_batch_resident(int device, const void *d_base,
         return st;
     SNAPPY_HIP_TRY(hipStreamSynchronize(s));
     finish_sha1_profile(lease);
+    return SNAPPY_OK;
+}
+
+extern "C" int snappy_sha1_last_plan(uint32_t path_end[4], double *planned_ms)
+{
+    if (!t_plan_valid || !path_end)
+        return SNAPPY_E_INVALID_ARG;
+    for (int k = 0; k < kSha1Paths; ++k)
+        path_end[k] = t_plan_end[k];
+    if (planned_ms)
+        *planned_ms = t_plan_ms;
     return SNAPPY_OK;
 }

@@ -1,21 +1,22 @@
-// SHA-1 batch kernels for gfx950.
+// SHA-1 batch kernel for gfx950.
 //
 // SHA-1 is serial inside one message (block i+1 needs the state after block i),
-// so all parallelism is across messages.  Two kernels cover the two regimes of
-// the reference's hash loops (/root/reference/Snappy/Core/SnapshotManager.cs:
-// 312-324, Snappy/Features/Mcdf/McdfManager.cs:36-63, Snappy/Data/
-// SnapshotMigrator.cs:62-86):
+// so all parallelism is across messages, and the time of a batch is bounded
+// below both by its largest message's chain and by its total work.  One kernel
+// covers the regimes of the reference's hash loops (/root/reference/Snappy/Core/
+// SnapshotManager.cs:312-324, Snappy/Features/Mcdf/McdfManager.cs:36-63,
+// Snappy/Data/SnapshotMigrator.cs:62-86) by spreading a message over a group of
+// G = 64, 16, 4 or 1 lanes of a wavefront:
 //
-//   sha1_lanes_kernel  one message per lane, 64 messages per wavefront.  Lanes
-//                      that finish a message pull the next one from a device
-//                      queue, so a wave stays full whatever the size mix.
-//                      Throughput path (many small files).
-//   sha1_wave_kernel   one message per wavefront.  The 64 lanes expand and
-//                      K-bias the message schedules of 64 consecutive blocks in
-//                      parallel (state-independent work) into their own
-//                      registers; the serial 80-round chain then hops from lane
-//                      to lane, one block per lane.  Latency path (few large
-//                      files).
+//   G > 1   each lane expands and K-biases the message schedule of one block
+//           (state-independent work, G blocks of a message in parallel) into
+//           its own registers; the serial 80-round chain then hops from lane to
+//           lane inside the group.  G = 64 gives the fastest chain for one
+//           message (412 instructions per block on the chain, against ~650 when
+//           one lane does everything); smaller groups trade chain speed for
+//           4x / 16x more messages per wave.
+//   G = 1   one message per lane, 64 per wave, 613 instructions per block and
+//           lane: bulk throughput (10^5 and more small files).
 #include "sha1_device.hpp"
 #include "sha1_launch.hpp"
 #include "wave_util.hpp"
@@ -25,225 +26,221 @@ namespace snappy {
 namespace {
 
 constexpr int kWave = 64;
-constexpr uint32_t kLaneBatch = 64;  // tasks a wave claims from the queue at a time
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & (kWave - 1); }
 
 // ---------------------------------------------------------------------------
-// One message per lane.
-// ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
-sha1_lanes_kernel(const uint8_t *__restrict__ base, const Sha1Task *__restrict__ tasks,
-                  uint32_t end, Sha1PlanState *__restrict__ state, uint8_t *__restrict__ digests)
-{
-    const uint32_t lane = lane_id();
-    const uint32_t first = __builtin_amdgcn_readfirstlane(state->n_wave);
-    uint32_t *queue = &state->queue_lane;
-    uint32_t h[5] = {0, 0, 0, 0, 0};
-    const uint8_t *p = nullptr;
-    uint64_t rem = 0, total = 0;
-    uint32_t out_index = 0;
-    // 0 = idle, 1 = message bytes (or its 0x80 block) next, 2 = length-only block next
-    uint32_t mode = 0;
-    // The wave claims task indices from the device queue kLaneBatch at a time and
-    // hands them to its idle lanes from this pool (all three values are uniform).
-    uint32_t pool_next = 0, pool_end = 0;
-    bool queue_empty = false;
-
-    for (;;) {
-        for (;;) {
-            const uint64_t need_mask = __ballot(mode == 0);
-            if (need_mask == 0)
-                break;
-            if (pool_next >= pool_end) {
-                if (queue_empty)
-                    break;
-                const uint32_t start = first + wave_claim(queue, kLaneBatch, lane);
-                if (start >= end) {
-                    queue_empty = true;
-                    break;
-                }
-                pool_next = start;
-                pool_end = (end - start < kLaneBatch) ? end : start + kLaneBatch;
-            }
-            const uint32_t rank =
-                static_cast<uint32_t>(__popcll(need_mask & ((1ull << lane) - 1ull)));
-            const uint32_t i = pool_next + rank;
-            if (mode == 0 && i < pool_end) {
-                const Sha1Task t = tasks[i];
-                p = base + t.offset;
-                rem = total = t.len;
-                out_index = t.out_index;
-#pragma unroll
-                for (int k = 0; k < 5; ++k)
-                    h[k] = kSha1Init[k];
-                mode = 1;
-            }
-            const uint32_t taken = static_cast<uint32_t>(__popcll(need_mask));
-            pool_next = (pool_end - pool_next < taken) ? pool_end : pool_next + taken;
-        }
-        if (__ballot(mode != 0) == 0)
-            break;
-        if (mode != 0) {
-            uint32_t w[16];
-            bool last = false;
-            if (mode == 1) {
-                if (rem >= 64) {
-                    // Memory latency is covered by the other waves on the SIMD (the
-                    // kernel runs at eight waves per SIMD), not by prefetching.
-                    load_block_be(p, w);
-                    p += 64;
-                    rem -= 64;
-                } else {
-                    last = load_tail_block_be(p, static_cast<uint32_t>(rem), total, w);
-                    if (!last)
-                        mode = 2;
-                }
-            } else {
-                make_length_block(total, w);
-                last = true;
-            }
-            sha1_compress(h, w);
-            if (last) {
-                store_digest(digests + 20ull * out_index, h);
-                mode = 0;
-            }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------
-// One message per wavefront.
+// One message per group of G lanes.
 // ---------------------------------------------------------------------------
 
-// A superblock is 64 consecutive 64-byte blocks of one message: lane j expands
-// block j's schedule (K already added) into 80 registers of its own.  The chain
-// state then visits the lanes in order: all lanes execute the 80 rounds, the lane
-// that currently holds the state does so on its own schedule registers, and one
-// DPP rotate per state word (wave_ror:1) hands the state to the next lane.  The
-// serial part of a block is therefore 400 round instructions + 5 adds + 5
-// rotates, with no memory or LDS access on the chain.
-constexpr int kSuper = 64;
-constexpr uint32_t kDppWaveRor1 = 0x13C;
-
-__device__ __forceinline__ uint32_t rotate_to_next_lane(uint32_t v)
+// A superblock is G consecutive 64-byte blocks of one message: lane j of the
+// group expands block j's schedule (K already added) into 80 registers of its
+// own.  The chain state then visits the group's lanes in order: all lanes
+// execute the 80 rounds, the lane that currently holds the state does so on its
+// own schedule registers, and one DPP rotate per state word hands the state to
+// the next lane of the group.  The serial part of a block is therefore 400 round
+// instructions + 5 adds + 5 rotates, with no memory or LDS access on the chain;
+// the expansion (~320 instructions) is paid once per G blocks.
+template <int G>
+__device__ __forceinline__ uint32_t rotate_in_group(uint32_t v)
 {
-    return __builtin_amdgcn_update_dpp(v, v, kDppWaveRor1, 0xF, 0xF, false);
+    if constexpr (G == 64)
+        return __builtin_amdgcn_update_dpp(v, v, 0x13C, 0xF, 0xF, false);  // wave_ror:1
+    else if constexpr (G == 16)
+        return __builtin_amdgcn_update_dpp(v, v, 0x121, 0xF, 0xF, false);  // row_ror:1
+    else if constexpr (G == 4)
+        return __builtin_amdgcn_update_dpp(v, v, 0x93, 0xF, 0xF, false);   // quad_perm:[3,0,1,2]
+    else
+        return v;
 }
 
-// Schedule words K + W[0..79] of the block whose 16 big-endian words are in w.
-__device__ __forceinline__ void expand_biased(uint32_t (&w)[16], uint32_t (&wk)[80])
+// Claims the next 64 / G messages of tasks [first, end) and hashes them, one per
+// group.  Returns false when the range was already exhausted.
+template <int G>
+__device__ __forceinline__ bool hop_once(const uint8_t *__restrict__ base,
+                                         const Sha1Task *__restrict__ tasks, uint32_t first,
+                                         uint32_t end, uint32_t *queue,
+                                         uint8_t *__restrict__ digests, uint32_t lane)
 {
+    constexpr uint32_t kGroups = kWave / G;
+    // With one lane per message a superblock is a single block, too short to cover
+    // the latency of the next block's loads: prefetch two blocks ahead there.
+    constexpr bool kDeep = (G == 1);
+    const uint32_t j = lane & (G - 1);  // position in the group
+    const uint32_t grp = lane / G;
+
+    const uint32_t i0 = first + wave_claim(queue, kGroups, lane);
+    if (i0 >= end)
+        return false;
+    // Groups past the end of the range idle through this round (no blocks).
+    const bool have = (G == 64) || i0 + grp < end;
+    const Sha1Task task = tasks[have ? i0 + grp : i0];
+    const uint8_t *msg = base + task.offset;
+    const uint64_t len = have ? task.len : 0;
+    const uint64_t n_full = len >> 6;
+    const uint32_t rem = static_cast<uint32_t>(len & 63u);
+    const uint64_t n_blocks = have ? n_full + (rem < 56 ? 1u : 2u) : 0;
+    const uint32_t shift = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(msg) & 3u);
+
+    // The state lives in one lane of the group at a time, lane 0 first.
+    uint32_t h[5];
 #pragma unroll
-    for (int t = 0; t < 80; ++t) {
-        const uint32_t wt = (t < 16) ? w[t] : sha1_schedule(w, t);
-        wk[t] = wt + kSha1K[t / 20];
-    }
-}
+    for (int k = 0; k < 5; ++k)
+        h[k] = kSha1Init[k];
 
-__global__ void __launch_bounds__(kWave)
-sha1_wave_kernel(const uint8_t *__restrict__ base, const Sha1Task *__restrict__ tasks,
-                 Sha1PlanState *__restrict__ state, uint8_t *__restrict__ digests)
-{
-    const uint32_t lane = lane_id();
-    const uint32_t n_tasks = __builtin_amdgcn_readfirstlane(state->n_wave);
-    uint32_t *queue = &state->queue_wave;
-
-    for (;;) {
-        const uint32_t i = wave_claim(queue, 1u, lane);
-        if (i >= n_tasks)
-            break;
-        const Sha1Task task = tasks[i];
-        const uint8_t *msg = base + task.offset;
-        const uint64_t len = task.len;
-        const uint64_t n_full = len >> 6;
-        const uint32_t rem = static_cast<uint32_t>(len & 63u);
-        const uint64_t n_blocks = n_full + (rem < 56 ? 1u : 2u);
-        const uint32_t shift = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(msg) & 3u);
-
-        // The state lives in one lane at a time, lane 0 first.
-        uint32_t h[5];
+    // Raw dwords of this lane's block in the coming superblock(s), loaded ahead
+    // so the chain does not wait for memory.
+    uint32_t raw[17], raw_next[kDeep ? 17 : 1];
 #pragma unroll
-        for (int k = 0; k < 5; ++k)
-            h[k] = kSha1Init[k];
-
-        // Raw dwords of this lane's block in the coming superblock, loaded one
-        // superblock ahead so the chain never waits for memory.
-        uint32_t raw[17];
+    for (int k = 0; k < 17; ++k)
+        raw[k] = 0;
+    if (j < n_full)
+        load_block_raw(msg + (static_cast<uint64_t>(j) << 6), shift, raw);
+    if constexpr (kDeep) {
 #pragma unroll
         for (int k = 0; k < 17; ++k)
-            raw[k] = 0;
-        if (lane < n_full)
-            load_block_raw(msg + (static_cast<uint64_t>(lane) << 6), shift, raw);
+            raw_next[k] = 0;
+        if (j + G < n_full)
+            load_block_raw(msg + (static_cast<uint64_t>(j + G) << 6), shift, raw_next);
+    }
 
-        uint32_t hops = 0;
-        for (uint64_t blk0 = 0; blk0 < n_blocks; blk0 += kSuper) {
-            const uint32_t nb =
-                static_cast<uint32_t>(n_blocks - blk0 < kSuper ? n_blocks - blk0 : kSuper);
+    for (uint64_t blk0 = 0;; blk0 += G) {
+        const uint64_t left = blk0 < n_blocks ? n_blocks - blk0 : 0;
+        if (G == 64 ? left == 0 : __ballot(left != 0) == 0)
+            break;
+        const uint32_t nb = left < G ? static_cast<uint32_t>(left) : static_cast<uint32_t>(G);
 
-            // Phase 1: lane j expands block blk0+j (lanes past the end idle).
+        // Phase 1: lane j prepares block blk0+j (lanes past the end idle).
+        uint32_t w[16];
+        {
+            const uint64_t b = blk0 + j;
+            if (b < n_full)
+                raw_block_to_be(raw, shift, w);
+            else if (b == n_full)
+                load_tail_block_be(msg + (n_full << 6), rem, len, w);
+            else
+                make_length_block(len, w);
+        }
+        if constexpr (G == 1) {
+            // One lane per message: nothing to share, so the schedule is expanded
+            // inside the rounds from a 16-word ring (613 instructions per block).
+#pragma unroll
+            for (int k = 0; k < 17; ++k)
+                raw[k] = raw_next[k];
+            if (blk0 + 2 < n_full)
+                load_block_raw(msg + ((blk0 + 2) << 6), shift, raw_next);
+            uint32_t moved[5] = {h[0], h[1], h[2], h[3], h[4]};
+            sha1_compress(moved, w);
+#pragma unroll
+            for (int k = 0; k < 5; ++k)
+                h[k] = nb ? moved[k] : h[k];
+        } else {
+            // K is added to the schedule words here, off the chain.
             uint32_t wk[80];
+#pragma unroll
+            for (int t = 0; t < 80; ++t) {
+                const uint32_t wt = (t < 16) ? w[t] : sha1_schedule(w, t);
+                wk[t] = wt + kSha1K[t / 20];
+            }
+            __builtin_amdgcn_sched_barrier(0);
             {
-                const uint64_t b = blk0 + lane;
-                uint32_t w[16];
-                if (b < n_full)
-                    raw_block_to_be(raw, shift, w);
-                else if (b == n_full)
-                    load_tail_block_be(msg + (n_full << 6), rem, len, w);
-                else
-                    make_length_block(len, w);
-                expand_biased(w, wk);
-                __builtin_amdgcn_sched_barrier(0);
-                const uint64_t nxt = b + kSuper;
+                const uint64_t nxt = blk0 + j + G;
                 if (nxt < n_full)
                     load_block_raw(msg + (nxt << 6), shift, raw);
             }
 
-            // Phase 2: the chain hops through the lanes.
-            for (uint32_t b = 0; b < nb; ++b) {
+            // Phase 2: the chain hops through the group's lanes.  Groups whose
+            // message has fewer blocks left than the wave's longest keep their
+            // state where it is.
+            for (uint32_t s = 0; G == 64 ? s < nb : __ballot(s < nb) != 0; ++s) {
                 uint32_t a = h[0], bb = h[1], c = h[2], d = h[3], e = h[4];
 #pragma unroll
                 for (int t = 0; t < 80; ++t)
                     sha1_round<true>(t, a, bb, c, d, e, wk[t]);
-                h[0] = rotate_to_next_lane(h[0] + a);
-                h[1] = rotate_to_next_lane(h[1] + bb);
-                h[2] = rotate_to_next_lane(h[2] + c);
-                h[3] = rotate_to_next_lane(h[3] + d);
-                h[4] = rotate_to_next_lane(h[4] + e);
-            }
-            hops += nb;
-        }
-        // The state ended in lane (hops mod 64); every lane stores the same bytes.
-        const uint32_t holder = hops & (kWave - 1);
-        uint32_t out[5];
+                const uint32_t moved[5] = {
+                    rotate_in_group<G>(h[0] + a), rotate_in_group<G>(h[1] + bb),
+                    rotate_in_group<G>(h[2] + c), rotate_in_group<G>(h[3] + d),
+                    rotate_in_group<G>(h[4] + e)};
+                const bool on = (G == 64) || s < nb;
 #pragma unroll
-        for (int k = 0; k < 5; ++k)
-            out[k] = __builtin_amdgcn_readlane(h[k], holder);
-        store_digest(digests + 20ull * task.out_index, out);
+                for (int k = 0; k < 5; ++k)
+                    h[k] = on ? moved[k] : h[k];
+            }
+        }
+    }
+    // After n_blocks hops the state sits in lane (n_blocks mod G) of the group.
+    if (have && j == static_cast<uint32_t>(n_blocks & (G - 1)))
+        store_digest(digests + 20ull * task.out_index, h);
+    return true;
+}
+
+// Every wave repeatedly takes the most urgent piece of work left: among the four
+// paths' next unclaimed messages, the one whose chain will run longest
+// (blocks x the path's time per block).  Within a path the messages are sorted
+// by size, so this hands out wave-sized pieces of work longest first across all
+// paths, which keeps the batch's finishing time close to max(longest chain,
+// total SIMD time / SIMDs).
+__global__ void __launch_bounds__(kWave)
+sha1_hop_kernel(const uint8_t *__restrict__ base, const Sha1Task *__restrict__ tasks,
+                Sha1PlanState *__restrict__ state, uint8_t *__restrict__ digests)
+{
+    const uint32_t lane = lane_id();
+    if (blockIdx.x >= gridDim.x / kMaxWavesPerSimd *
+                          __builtin_amdgcn_readfirstlane(state->waves_per_simd))
+        return;
+    uint32_t lo[kSha1Paths], hi[kSha1Paths];
+    float chain[kSha1Paths];
+    bool open[kSha1Paths];
+#pragma unroll
+    for (int k = 0; k < kSha1Paths; ++k) {
+        lo[k] = k ? __builtin_amdgcn_readfirstlane(state->path_end[k - 1]) : 0u;
+        hi[k] = __builtin_amdgcn_readfirstlane(state->path_end[k]);
+        chain[k] = __builtin_amdgcn_readfirstlane(state->chain_ns[k]);
+        open[k] = lo[k] < hi[k];
+    }
+    for (;;) {
+        int best = -1;
+        float best_time = -1.f;
+#pragma unroll
+        for (int k = 0; k < kSha1Paths; ++k) {
+            if (!open[k])
+                continue;
+            const uint32_t next = __builtin_amdgcn_readfirstlane(
+                __hip_atomic_load(&state->queue[k].next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            if (next >= hi[k] - lo[k]) {
+                open[k] = false;
+                continue;
+            }
+            const uint64_t len = tasks[lo[k] + next].len;
+            const float t = static_cast<float>((len + 8) / 64 + 1) * chain[k];
+            if (t > best_time) {
+                best_time = t;
+                best = k;
+            }
+        }
+        if (best < 0)
+            break;
+        // A failed claim only means another wave was quicker: look again.
+        switch (best) {
+        case 0: hop_once<64>(base, tasks, lo[0], hi[0], &state->queue[0].next, digests, lane); break;
+        case 1: hop_once<16>(base, tasks, lo[1], hi[1], &state->queue[1].next, digests, lane); break;
+        case 2: hop_once<4>(base, tasks, lo[2], hi[2], &state->queue[2].next, digests, lane); break;
+        default: hop_once<1>(base, tasks, lo[3], hi[3], &state->queue[3].next, digests, lane); break;
+        }
     }
 }
 
 }  // namespace
 
-hipError_t launch_sha1_lanes(const uint8_t *d_base, const Sha1Task *d_tasks, uint32_t n,
-                             Sha1PlanState *d_state, uint8_t *d_digests, int blocks,
-                             hipStream_t stream)
+hipError_t launch_sha1_hop(const uint8_t *d_base, const Sha1Task *d_tasks, Sha1PlanState *d_state,
+                           uint8_t *d_digests, uint32_t n, uint32_t n_simd, hipStream_t stream)
 {
-    if (n == 0 || blocks <= 0)
+    if (n == 0)
         return hipSuccess;
-    hipLaunchKernelGGL(sha1_lanes_kernel, dim3(blocks), dim3(256), 0, stream, d_base, d_tasks, n,
-                       d_state, d_digests);
-    return hipGetLastError();
-}
-
-hipError_t launch_sha1_wave(const uint8_t *d_base, const Sha1Task *d_tasks,
-                            Sha1PlanState *d_state, uint8_t *d_digests, int waves,
-                            hipStream_t stream)
-{
-    if (waves <= 0)
-        return hipSuccess;
-    hipLaunchKernelGGL(sha1_wave_kernel, dim3(waves), dim3(kWave), 0, stream, d_base, d_tasks,
-                       d_state, d_digests);
+    // A multiple of kMaxWavesPerSimd, so that the kernel's cut-off is exact.
+    const uint32_t per = n < n_simd ? n : n_simd;
+    hipLaunchKernelGGL(sha1_hop_kernel, dim3(per * kMaxWavesPerSimd), dim3(kWave), 0, stream,
+                       d_base, d_tasks, d_state, d_digests);
     return hipGetLastError();
 }
 

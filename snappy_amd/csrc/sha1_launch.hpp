@@ -11,39 +11,56 @@ namespace snappy {
 
 constexpr int kPlanBuckets = 512;
 
-// Planner output and the kernels' work queues, one per batch in device memory.
-// Zeroed by launch_sha1_plan, filled by its kernels, read by the SHA-1 kernels.
-struct Sha1PlanState {
-    uint32_t n_wave;                  // tasks [0, n_wave) go to the wave kernel
-    uint32_t reserved0;
-    unsigned long long total_blocks;  // padded 64-byte blocks over all messages
-    unsigned long long max_blocks;    // of the largest message
-    uint32_t reserved1[26];
-    uint32_t queue_wave;              // next task of the wave kernel (own 128-byte line)
-    uint32_t reserved2[31];
-    uint32_t queue_lane;              // next task of the lane kernel, counted from n_wave
-    uint32_t reserved3[31];
-    uint32_t hist[kPlanBuckets];      // messages per size bucket, largest bucket first
-    uint32_t cursor[kPlanBuckets];    // running write position per bucket
+// A batch is sorted by descending size and cut into four consecutive ranges, one
+// per execution path: a message is spread over a group of 64, 16, 4 or 1 lanes
+// of a wavefront (so a wave carries 1, 4, 16 or 64 messages).  The wider the
+// group, the faster one message's chain and the more SIMD time a byte costs.
+constexpr int kSha1Paths = 4;
+constexpr int kHopGroupLanes[kSha1Paths] = {64, 16, 4, 1};
+
+// What the planner needs to know about the paths (all times in nanoseconds per
+// 64-byte block): chain_ns = how fast one message advances when its wave has a
+// SIMD to itself; simd_ns = SIMD time one block costs (chain_ns / messages per
+// wave).
+struct Sha1CostModel {
+    double chain_ns[kSha1Paths];
+    double simd_ns[kSha1Paths];
+    double slow_path_margin;  // paths 1..3 only take messages whose chain fits in this share of T
+    uint32_t n_simd;
+    int forced_path;          // >= 0: everything takes this path (testing / tuning)
+    int forced_waves;         // > 0: waves per SIMD (testing / tuning)
 };
 
-// Sorts the n messages by descending padded size into d_tasks and decides the
-// split between the kernels (see sha1_plan.hip).  forced_min_blocks >= 0
-// overrides the split: messages of more blocks than that go to the wave kernel.
+// Planner output and the kernel's work queues, one per batch in device memory.
+// Zeroed by launch_sha1_plan, filled by its kernels, read by the SHA-1 kernel.
+struct Sha1PlanState {
+    uint32_t path_end[kSha1Paths];    // path k owns tasks [path_end[k-1], path_end[k]); path_end[-1] = 0
+    unsigned long long total_blocks;  // padded 64-byte blocks over all messages
+    unsigned long long max_blocks;    // of the largest message
+    double planned_ns;                // the model's finishing time for the chosen cut
+    float chain_ns[kSha1Paths];       // the model's chain times, for the kernel's work order
+    uint32_t waves_per_simd;          // 1: chains decide the finishing time; 2: bulk throughput
+    uint32_t reserved1[16];
+    struct alignas(128) Queue {       // next task of a path, counted from its range's start
+        uint32_t next;
+    } queue[kSha1Paths];
+    uint32_t hist[kPlanBuckets];      // messages per size bucket, largest bucket first
+    uint32_t cursor[kPlanBuckets];    // running write position per bucket
+    unsigned long long blocks[kPlanBuckets];  // padded blocks per bucket
+};
+
+// Sorts the n messages by descending padded size into d_tasks and cuts the
+// sorted list into the paths' ranges (see sha1_plan.hip).
 hipError_t launch_sha1_plan(const uint64_t *d_offsets, const uint64_t *d_lengths, uint32_t n,
-                            Sha1PlanState *d_state, Sha1Task *d_tasks, uint32_t n_simd,
-                            double ns_wave, double ns_lane, double simd_ns_lane,
-                            long long forced_min_blocks, hipStream_t stream);
-
-// Tasks [state->n_wave, n) of d_tasks, one message per lane; `blocks` workgroups of 256.
-hipError_t launch_sha1_lanes(const uint8_t *d_base, const Sha1Task *d_tasks, uint32_t n,
-                             Sha1PlanState *d_state, uint8_t *d_digests, int blocks,
-                             hipStream_t stream);
-
-// Tasks [0, state->n_wave) of d_tasks, one message per wavefront; `waves`
-// single-wave workgroups.
-hipError_t launch_sha1_wave(const uint8_t *d_base, const Sha1Task *d_tasks,
-                            Sha1PlanState *d_state, uint8_t *d_digests, int waves,
+                            Sha1PlanState *d_state, Sha1Task *d_tasks, const Sha1CostModel &model,
                             hipStream_t stream);
+
+// Hashes the planned batch.  n_simd * kMaxWavesPerSimd single-wave workgroups are
+// launched (fewer for small batches); those beyond the planner's waves_per_simd
+// leave at once, the others take work, longest chains first, until none is left.
+constexpr int kMaxWavesPerSimd = 2;
+hipError_t launch_sha1_hop(const uint8_t *d_base, const Sha1Task *d_tasks,
+                           Sha1PlanState *d_state, uint8_t *d_digests, uint32_t n,
+                           uint32_t n_simd, hipStream_t stream);
 
 }  // namespace snappy

@@ -2,12 +2,12 @@
 //
 // The reference hashes its files one after another in list order
 // (/root/reference/Snappy/Core/SnapshotManager.cs:312-324).  On the GPU the order
-// matters for the makespan: messages are handed out largest first, and the few
-// that would outlast the batch on the one-message-per-lane kernel go to the
-// one-message-per-wave kernel instead.  With 10^6 files that ordering costs more
-// on the host than the hashing costs on the GPU, so it is done here: a bucket
-// sort by padded block count (8 buckets per octave, descending) in three small
-// kernels, and the split point written to a header the SHA-1 kernels read.
+// matters for the makespan: messages are handed out largest first, and the larger
+// a message, the more lanes of a wavefront work on it (see sha1_kernels.hip).
+// With 10^6 files that ordering costs more on the host than the hashing costs on
+// the GPU, so it is done here: a bucket sort by padded block count (8 buckets
+// per octave, descending) in three small kernels, and the cuts between the
+// execution paths written to a header the SHA-1 kernels read.
 #include "sha1_launch.hpp"
 
 namespace snappy {
@@ -42,9 +42,12 @@ __global__ void __launch_bounds__(kPlanThreads)
 plan_histogram(const uint64_t *__restrict__ lengths, uint32_t n, Sha1PlanState *__restrict__ st)
 {
     __shared__ uint32_t hist[kPlanBuckets];
+    __shared__ unsigned long long sums[kPlanBuckets];
     __shared__ unsigned long long s_total, s_max;
-    for (int k = threadIdx.x; k < kPlanBuckets; k += kPlanThreads)
+    for (int k = threadIdx.x; k < kPlanBuckets; k += kPlanThreads) {
         hist[k] = 0;
+        sums[k] = 0;
+    }
     if (threadIdx.x == 0) {
         s_total = 0;
         s_max = 0;
@@ -59,33 +62,56 @@ plan_histogram(const uint64_t *__restrict__ lengths, uint32_t n, Sha1PlanState *
             const uint64_t b = padded_blocks(lengths[i]);
             total += b;
             mx = b > mx ? b : mx;
-            atomicAdd(&hist[kPlanBuckets - 1 - size_bucket(b)], 1u);
+            const uint32_t pos = kPlanBuckets - 1 - size_bucket(b);
+            atomicAdd(&hist[pos], 1u);
+            atomicAdd(&sums[pos], static_cast<unsigned long long>(b));
         }
     }
     atomicAdd(&s_total, total);
     atomicMax(&s_max, mx);
     __syncthreads();
     for (int k = threadIdx.x; k < kPlanBuckets; k += kPlanThreads)
-        if (hist[k])
+        if (hist[k]) {
             atomicAdd(&st->hist[k], hist[k]);
+            atomicAdd(&st->blocks[k], sums[k]);
+        }
     if (threadIdx.x == 0) {
         atomicAdd(&st->total_blocks, s_total);
         atomicMax(&st->max_blocks, s_max);
     }
 }
 
-// Pass 2 (one workgroup): bucket start positions and the split between kernels.
-// A message goes to the wave kernel when the lane kernel would keep it past
-// ~80 % of the batch's lower bound max(longest chain, lane-kernel issue time);
-// with no more messages than SIMDs every message gets a wave of its own.
+// Pass 2 (one workgroup): bucket start positions and the cuts between paths.
+//
+// The batch cannot finish before its largest message's chain on the fastest
+// path, nor before its total SIMD time has been spent on the n_simd SIMDs.  For a
+// finishing time T a bucket may take path k when its largest possible message
+// would finish well in time on that path (edge * chain_ns[k] <= margin * T, so
+// that work on the slower paths comes in pieces that still pack into T), and
+// the cheapest such path is the best one for it.  T is feasible when the SIMD time of that
+// assignment fits into T * n_simd; the smallest feasible T is found by
+// bisection and its assignment becomes the plan.  Sizes fall along the sorted
+// list, so every path's buckets are consecutive.
+__device__ __forceinline__ int cheapest_path(double edge_blocks, double t, const Sha1CostModel &m,
+                                             int last_path)
+{
+    for (int k = last_path; k > 0; --k)
+        if (edge_blocks * m.chain_ns[k] <= m.slow_path_margin * t)
+            return k;
+    return 0;
+}
+
 __global__ void __launch_bounds__(kPlanBuckets)
-plan_scan(Sha1PlanState *__restrict__ st, uint32_t n, uint32_t n_simd, double ns_wave,
-          double ns_lane, double simd_ns_lane, long long forced_min_blocks)
+plan_scan(Sha1PlanState *__restrict__ st, uint32_t n, Sha1CostModel m)
 {
     __shared__ uint32_t scan[kPlanBuckets];
+    __shared__ uint32_t used[kPlanBuckets];  // positions of the non-empty buckets
+    __shared__ uint32_t n_used;
     const uint32_t k = threadIdx.x;
     const uint32_t count = st->hist[k];
     scan[k] = count;
+    if (k == 0)
+        n_used = 0;
     __syncthreads();
     for (uint32_t d = 1; d < kPlanBuckets; d <<= 1) {
         const uint32_t v = (k >= d) ? scan[k - d] : 0u;
@@ -93,29 +119,78 @@ plan_scan(Sha1PlanState *__restrict__ st, uint32_t n, uint32_t n_simd, double ns
         scan[k] += v;
         __syncthreads();
     }
-    const uint32_t start = scan[k] - count;
-    st->cursor[k] = start;
+    st->cursor[k] = scan[k] - count;
+    if (count)
+        used[atomicAdd(&n_used, 1u)] = k;
+    __syncthreads();
+    if (k != 0)
+        return;
 
-    const double t_star = fmax(static_cast<double>(st->max_blocks) * ns_wave,
-                               static_cast<double>(st->total_blocks) * simd_ns_lane /
-                                   static_cast<double>(n_simd));
-    double thr = (n <= n_simd) ? 0.0 : 0.8 * t_star / ns_lane;
-    if (forced_min_blocks >= 0)
-        thr = static_cast<double>(forced_min_blocks);
-    // Position k holds bucket (kPlanBuckets-1-k); whole buckets above the threshold
-    // go to the wave kernel.  They are a prefix of the sorted order.
-    const bool above = bucket_floor(kPlanBuckets - 1 - k) > thr || thr == 0.0;
-    __shared__ uint32_t n_wave;
-    if (k == 0)
-        n_wave = 0;
-    __syncthreads();
-    if (above && count)
-        atomicMax(&n_wave, start + count);
-    __syncthreads();
-    if (k == 0) {
-        const uint32_t cap = 2u * n_simd;
-        st->n_wave = n_wave < cap ? n_wave : cap;
+    uint32_t cut[kSha1Paths];
+    for (int q = 0; q < kSha1Paths; ++q)
+        cut[q] = 0;
+    double planned = 0.0;
+    uint32_t waves = 1;
+    if (m.forced_path >= 0) {
+        for (int q = m.forced_path; q < kSha1Paths; ++q)
+            cut[q] = n;
+    } else {
+        const double max_blocks = static_cast<double>(st->max_blocks);
+        const double total = static_cast<double>(st->total_blocks);
+        const double simds = static_cast<double>(m.n_simd);
+        const int last_path = kSha1Paths - 1;
+        double lo = max_blocks * m.chain_ns[0];
+        double hi = lo + total * m.simd_ns[0] / simds;  // everything on path 0 fits into this
+        for (int it = 0; it < 24 && hi > 1.002 * lo; ++it) {
+            const double t = sqrt(lo * hi);
+            double work = 0.0;
+            for (uint32_t u = 0; u < n_used; ++u) {
+                const uint32_t pos = used[u];
+                const double edge = fmin(bucket_floor(kPlanBuckets - pos), max_blocks);
+                work += static_cast<double>(st->blocks[pos]) *
+                        m.simd_ns[cheapest_path(edge, t, m, last_path)];
+            }
+            if (work <= t * simds)
+                hi = t;
+            else
+                lo = t;
+        }
+        planned = hi;
+        for (uint32_t u = 0; u < n_used; ++u) {
+            const uint32_t pos = used[u];
+            const double edge = fmin(bucket_floor(kPlanBuckets - pos), max_blocks);
+            const int path = cheapest_path(edge, hi, m, last_path);
+            if (scan[pos] > cut[path])
+                cut[path] = scan[pos];
+        }
+        // Ends of empty paths follow their predecessor; the last path ends the list.
+        for (int q = 1; q < kSha1Paths; ++q)
+            if (cut[q] < cut[q - 1])
+                cut[q] = cut[q - 1];
+        cut[kSha1Paths - 1] = n;
+        // When nearly all the SIMD time goes into one-lane groups the batch is a
+        // throughput job: a second wave per SIMD then hides what the first one
+        // waits for.  Otherwise chains matter and a shared SIMD would halve their speed.
+        double bulk = 0.0, all = 0.0;
+        for (uint32_t u = 0; u < n_used; ++u) {
+            const uint32_t pos = used[u];
+            const double edge = fmin(bucket_floor(kPlanBuckets - pos), max_blocks);
+            const int path = cheapest_path(edge, hi, m, last_path);
+            const double w = static_cast<double>(st->blocks[pos]) * m.simd_ns[path];
+            all += w;
+            if (path == kSha1Paths - 1)
+                bulk += w;
+        }
+        waves = (bulk >= 0.9 * all && n >= 128u * m.n_simd) ? 2u : 1u;
     }
+    for (int q = 0; q < kSha1Paths; ++q)
+        st->path_end[q] = cut[q];
+    for (int q = 0; q < kSha1Paths; ++q)
+        st->chain_ns[q] = static_cast<float>(m.chain_ns[q]);
+    if (m.forced_waves > 0)
+        waves = m.forced_waves < kMaxWavesPerSimd ? m.forced_waves : kMaxWavesPerSimd;
+    st->waves_per_simd = waves;
+    st->planned_ns = planned;
 }
 
 // Pass 3: scatter the tasks to their bucket ranges.  A workgroup counts its files
@@ -163,9 +238,8 @@ plan_scatter(const uint64_t *__restrict__ offsets, const uint64_t *__restrict__ 
 }  // namespace
 
 hipError_t launch_sha1_plan(const uint64_t *d_offsets, const uint64_t *d_lengths, uint32_t n,
-                            Sha1PlanState *d_state, Sha1Task *d_tasks, uint32_t n_simd,
-                            double ns_wave, double ns_lane, double simd_ns_lane,
-                            long long forced_min_blocks, hipStream_t stream)
+                            Sha1PlanState *d_state, Sha1Task *d_tasks, const Sha1CostModel &model,
+                            hipStream_t stream)
 {
     if (n == 0)
         return hipSuccess;
@@ -176,8 +250,7 @@ hipError_t launch_sha1_plan(const uint64_t *d_offsets, const uint64_t *d_lengths
     const uint32_t groups = (n + per_group - 1) / per_group;
     hipLaunchKernelGGL(plan_histogram, dim3(groups), dim3(kPlanThreads), 0, stream, d_lengths, n,
                        d_state);
-    hipLaunchKernelGGL(plan_scan, dim3(1), dim3(kPlanBuckets), 0, stream, d_state, n, n_simd,
-                       ns_wave, ns_lane, simd_ns_lane, forced_min_blocks);
+    hipLaunchKernelGGL(plan_scan, dim3(1), dim3(kPlanBuckets), 0, stream, d_state, n, model);
     hipLaunchKernelGGL(plan_scatter, dim3(groups), dim3(kPlanThreads), 0, stream, d_offsets,
                        d_lengths, n, d_state, d_tasks);
     return hipGetLastError();

@@ -58,6 +58,7 @@ SYMBOLS = [
     ("snappy_mcdf_import_to_dir", _i, [ctypes.c_char_p, ctypes.c_char_p, _vp, _u64]),
     ("snappy_profile_enable", None, [_i]),
     ("snappy_profile_last_ms", ctypes.c_float, [_i]),
+    ("snappy_sha1_last_plan", _i, [ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_double)]),
 ]
 
 

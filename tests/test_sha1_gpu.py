@@ -9,10 +9,22 @@ import helpers as H
 
 pytestmark = pytest.mark.gpu
 
+# Sends every message of a batch down one execution path: 64, 16, 4 or 1 lanes of a
+# wavefront per message (0..3).  Unset: the planner cuts the batch itself.
+FORCE = "SNAPPY_SHA1_FORCE_PATH"
+ALL_PATHS = ("0", "1", "2", "3")
+
+
+def force_path(path):
+    if path is None:
+        os.environ.pop(FORCE, None)
+    else:
+        os.environ[FORCE] = path
+
 
 @pytest.fixture(autouse=True)
 def _clean_env():
-    keep = {k: os.environ.get(k) for k in ("SNAPPY_WAVE_MIN_BLOCKS",)}
+    keep = {k: os.environ.get(k) for k in (FORCE,)}
     yield
     for k, v in keep.items():
         if v is None:
@@ -43,8 +55,8 @@ def test_golden_splitmix_single_calls(snappy):
         assert snappy.get_hash(data) == row["sha1"], row
 
 
-def test_golden_splitmix_one_batch_both_kernels(snappy, oracle):
-    """All golden rows in one packed batch, once per kernel path."""
+def test_golden_splitmix_one_batch_every_path(snappy, oracle):
+    """All golden rows in one packed batch, once per execution path."""
     g = H.load_golden("sha1_golden.json")
     blobs = [H.splitmix_bytes(r["len"], H.file_seed(r["index"])) for r in g["splitmix"]]
     want = [r["sha1"] for r in g["splitmix"]]
@@ -53,22 +65,19 @@ def test_golden_splitmix_one_batch_both_kernels(snappy, oracle):
     offsets = np.concatenate([[0], np.cumsum(lengths)[:-1]]).astype(np.uint64)
     from snappy_amd.crypto import digests_to_hex
 
-    for wave_min in ("1000000000", "0", None):   # lanes only / wave only / planner's choice
-        if wave_min is None:
-            os.environ.pop("SNAPPY_WAVE_MIN_BLOCKS", None)
-        else:
-            os.environ["SNAPPY_WAVE_MIN_BLOCKS"] = wave_min
+    for path in ALL_PATHS + (None,):
+        force_path(path)
         got = digests_to_hex(snappy.sha1_batch(base, offsets, lengths))
-        assert got == want, wave_min
+        assert got == want, path
 
 
-@pytest.mark.parametrize("wave_min", ["1000000000", "0"])
-def test_random_unaligned_slices_vs_oracle(snappy, oracle, wave_min):
+@pytest.mark.parametrize("path", ALL_PATHS)
+def test_random_unaligned_slices_vs_oracle(snappy, oracle, path):
     """Slices at every byte alignment, overlapping, empty, and ending at the buffer's last byte."""
-    os.environ["SNAPPY_WAVE_MIN_BLOCKS"] = wave_min
+    force_path(path)
     rng = np.random.default_rng(11)
     base = rng.integers(0, 256, size=300_000, dtype=np.uint8)
-    n = 3000 if wave_min != "0" else 700
+    n = 700 if path == "0" else 3000
     lengths = rng.integers(0, 2500, size=n).astype(np.uint64)
     lengths[::97] = 0
     offsets = rng.integers(0, 300_000 - 2500, size=n).astype(np.uint64)
@@ -90,10 +99,10 @@ def test_every_length_0_to_300_every_alignment(snappy, oracle):
             lens.append(n)
     offs = np.array(offs, dtype=np.uint64)
     lens = np.array(lens, dtype=np.uint64)
-    for wave_min in ("1000000000", "0"):
-        os.environ["SNAPPY_WAVE_MIN_BLOCKS"] = wave_min
-        assert np.array_equal(snappy.sha1_batch(base, offs, lens),
-                              oracle.sha1_batch_np(base, offs, lens)), wave_min
+    want = oracle.sha1_batch_np(base, offs, lens)
+    for path in ALL_PATHS:
+        force_path(path)
+        assert np.array_equal(snappy.sha1_batch(base, offs, lens), want), path
 
 
 def test_separate_buffers_and_single_calls(snappy, oracle):
@@ -192,13 +201,25 @@ def test_fully_resident_batch(snappy, oracle):
         d_off = torch.from_numpy(offsets).cuda()
         d_len = torch.from_numpy(lengths).cuda()
         d_dig = torch.zeros(n * 20, dtype=torch.uint8, device="cuda")
-        for forced in (None, "0", "1000000000"):
-            if forced is None:
-                os.environ.pop("SNAPPY_WAVE_MIN_BLOCKS", None)
-            else:
-                os.environ["SNAPPY_WAVE_MIN_BLOCKS"] = forced
+        for forced in (None,) + ALL_PATHS:
+            force_path(forced)
             d_dig.zero_()
             sha1_batch_resident(0, dev.data_ptr(), d_off.data_ptr(), d_len.data_ptr(), n, d_dig.data_ptr())
             got = d_dig.cpu().numpy().reshape(n, 20)
             want = oracle.sha1_batch_np(host, offsets.astype(np.uint64), lengths.astype(np.uint64))
             assert np.array_equal(got, want), (n, hi, forced)
+
+
+def test_ragged_groups_and_partial_waves(snappy, oracle):
+    """Groups of one wave holding messages of very different block counts (some empty,
+    some ending mid-superblock), and message counts that leave groups of the last wave idle."""
+    rng = np.random.default_rng(51)
+    base = rng.integers(0, 256, size=2 << 20, dtype=np.uint8)
+    for n in (1, 3, 5, 17, 63, 65, 130):
+        lengths = rng.choice(np.array([0, 1, 55, 56, 63, 64, 119, 120, 128, 1000, 4096, 4159, 70_001,
+                                       300_000], dtype=np.uint64), size=n)
+        offsets = rng.integers(0, base.size - 300_000, size=n).astype(np.uint64)
+        want = oracle.sha1_batch_np(base, offsets, lengths)
+        for path in ALL_PATHS + (None,):
+            force_path(path)
+            assert np.array_equal(snappy.sha1_batch(base, offsets, lengths), want), (n, path)
