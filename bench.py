@@ -230,7 +230,7 @@ def extra_workloads(args, lib, native, torch, device, local_rank):
     """The other single-GPU configurations, measured briefly after the headline run so that one
     bench line also carries the small-file (throughput) and MCDF (LZ4 decode) kernels' rooflines."""
     res = {}
-    # 10^6 files of 4-32 KB: the one-message-per-lane kernel.
+    # 10^6 files of 4-32 KB: one message per lane, the throughput regime.
     rng = np.random.default_rng(0x534E4151)
     lengths = make_sizes("small", rng, 1.0)
     offsets = np.concatenate([[0], np.cumsum(lengths)[:-1]]).astype(np.uint64)
@@ -262,10 +262,13 @@ def extra_workloads(args, lib, native, torch, device, local_rank):
         "value": total / (np.mean(t_ms) * 1e-3) / GB, "unit": "GB/s", "ms_per_step": float(np.mean(t_ms)),
         "roofline": {"bound": "hbm", "achieved": algo / (km * 1e-3) / GB, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": algo / (km * 1e-3) / GB / HBM_PEAK_GBS,
-                     "kernel": "sha1_lanes_kernel", "kernel_ms": km, "algorithmic_bytes_per_launch": algo,
-                     "valu_ceiling_GBps": 4200.0,
-                     "note": "integer-VALU bound: 613 instructions per 64-byte block; 4.2 TB/s is the "
-                             "measured register-only compression ceiling (tools/ubench_sha1.hip)"},
+                     "traffic": measured_traffic("small", 1.0),
+                     "kernel": "sha1_hop_kernel", "kernel_ms": km, "algorithmic_bytes_per_launch": algo,
+                     "plan": last_plan(lib),
+                     "alu_peak_GBps": 4200.0, "alu_frac": algo / (km * 1e-3) / GB / 4200.0,
+                     "note": "integer-ALU bound: 613 instructions per 64-byte block; 4.2 TB/s is the "
+                             "measured register-only compression ceiling at full clock "
+                             "(tools/ubench_sha1.hip); under this load the clock settles near 1.7 GHz"},
         "digests_match_hashlib_sample": bool(ok)}
     del buf
     torch.cuda.empty_cache()
@@ -313,9 +316,97 @@ def cpu_baseline(host_sample: np.ndarray, offsets, lengths):
         res["openssl_1core_value"] = float(ln.sum()) / dt2 / GB
         ok = bytes(md) == out[n - 1].tobytes()
         res["openssl_agrees_with_port"] = bool(ok)
+        # All cores this job may use, one file per thread at a time (ctypes drops the GIL).
+        from concurrent.futures import ThreadPoolExecutor
+
+        cores = max(1, min(16, os.cpu_count() or 1))
+
+        def one(i):
+            buf20 = (ctypes.c_uint8 * 20)()
+            crypto.SHA1(base + int(off[i]), int(ln[i]), buf20)
+
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(cores) as pool:
+            list(pool.map(one, range(n)))
+        dt3 = time.perf_counter() - t0
+        res["openssl_allcore_value"] = float(ln.sum()) / dt3 / GB
+        res["openssl_allcore_threads"] = cores
     except OSError:
         pass
+    res.update(cpu_info())
     return res, out
+
+
+def cpu_info():
+    model, sha_ni = "unknown", None
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name") and model == "unknown":
+                    model = line.split(":", 1)[1].strip()
+                if line.startswith("flags") and sha_ni is None:
+                    sha_ni = " sha_ni" in line
+    except OSError:
+        pass
+    return {"cpu_model": model, "cpu_has_sha_ni": sha_ni}
+
+
+def h2d_bandwidth(torch, device):
+    """Measured pinned host -> HBM copy rate (GB/s), the ceiling of any end-to-end number."""
+    n = 1 << 30
+    src = torch.empty(n, dtype=torch.uint8, pin_memory=True)
+    dst = torch.empty(n, dtype=torch.uint8, device=device)
+    dst.copy_(src, non_blocking=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        dst.copy_(src, non_blocking=True)
+    torch.cuda.synchronize()
+    return 3 * n / (time.perf_counter() - t0) / GB
+
+
+def end_to_end(lib, native, torch, buf, offsets, lengths, total_bytes, digests, dist):
+    """The same corpus starting in host memory: one snappy_sha1_batch call moves it over PCIe,
+    hashes it and returns the digests.  Timed from page-locked memory (snappy_host_alloc) and,
+    on rank 0, from ordinary pageable memory as well."""
+    n = len(lengths)
+    ptr = ctypes.c_void_p()
+    native.check(lib.snappy_host_alloc(total_bytes + 64, ctypes.byref(ptr)), "snappy_host_alloc")
+    pinned = np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(ctypes.c_uint8)), shape=(total_bytes + 64,))
+    step = 1 << 30
+    for lo in range(0, total_bytes, step):
+        hi = min(lo + step, total_bytes)
+        pinned[lo:hi] = buf[lo:hi].cpu().numpy()
+    d2 = np.zeros((n, 20), dtype=np.uint8)
+
+    def run(base_ptr):
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        t0 = time.perf_counter()
+        native.check(lib.snappy_sha1_batch(base_ptr, offsets.ctypes.data, lengths.ctypes.data, n,
+                                           d2.ctypes.data), "snappy_sha1_batch")
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    run(ptr.value)  # first call sizes the library's device arena
+    t_pinned = min(run(ptr.value) for _ in range(2))
+    same = bool(np.array_equal(d2, digests))
+    out = {"pinned_seconds": t_pinned, "digests_match_resident_run": same}
+    if dist is None and total_bytes <= 20 * GB:
+        pageable = np.empty(total_bytes + 64, dtype=np.uint8)
+        pageable[:] = pinned
+        run(pageable.ctypes.data)
+        out["pageable_seconds"] = min(run(pageable.ctypes.data) for _ in range(2))
+        out["pageable_digests_match"] = bool(np.array_equal(d2, digests))
+        del pageable
+    del pinned
+    native.check(lib.snappy_host_free(ptr), "snappy_host_free")
+    return out
 
 
 def dry_run(args, rank, world):
@@ -357,6 +448,18 @@ def dry_run(args, rank, world):
         dist.destroy_process_group()
 
 
+def measured_traffic(workload, scale):
+    """HBM bytes per launch from the committed rocprofv3 counter pass for this workload
+    (profiles/hbm_traffic.json; collected and corrected as that file says), or None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
+            rows = json.load(f)
+    except (OSError, ValueError):
+        return None
+    row = rows.get(workload) if scale == 1.0 else None
+    return row.get("hbm_bytes_per_launch") if row else None
+
+
 def last_plan(lib):
     """How the planner cut the last batch: files per execution path and its expected time."""
     import ctypes
@@ -386,13 +489,23 @@ def main():
     ap.add_argument("--cpu-sample-gb", type=float, default=4.0)
     ap.add_argument("--no-extra", action="store_true",
                     help="skip the brief small-file and MCDF measurements appended to the default run")
-    ap.add_argument("--e2e", action="store_true",
-                    help="also time the host-pointer entry point (PCIe copy inside the call) on the same corpus")
+    ap.add_argument("--e2e-max-gb", type=float, default=40.0,
+                    help="largest per-GPU corpus for which the end-to-end leg (a host copy of the corpus) is run")
+    ap.add_argument("--no-e2e", action="store_true",
+                    help="skip the end-to-end leg (same corpus from host memory through snappy_sha1_batch)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+
+    if world > 1 and not args.cpu_dry_run:
+        # One process per GPU: make this rank's GPU the only one its HIP runtime sees, so
+        # that the host-pointer entry points (which use every visible device) stay on it.
+        visible = os.environ.get("HIP_VISIBLE_DEVICES")
+        ids = [v for v in visible.split(",") if v] if visible else None
+        os.environ["HIP_VISIBLE_DEVICES"] = ids[local_rank] if ids and local_rank < len(ids) else str(local_rank)
+        local_rank = 0
 
     import torch
 
@@ -481,6 +594,10 @@ def main():
     else:
         job_bytes = float(total_bytes)
 
+    e2e = None
+    if not args.no_e2e and total_bytes <= args.e2e_max_gb * GB:
+        e2e = end_to_end(lib, native, torch, buf, offsets, lengths, total_bytes, digests, dist)
+
     if rank != 0:
         if dist is not None:
             dist.barrier()
@@ -534,24 +651,35 @@ def main():
         },
     }
 
+    # Integer-ALU view of the same kernel time: SHA-1 is 613 vector instructions per
+    # 64-byte block on gfx950, and a CU retires 64 int32 lane-operations per clock.
+    props = torch.cuda.get_device_properties(device)
+    alu_peak = props.multi_processor_count * 64 * 2.4e9 / 613 * 64 / GB
+    # One wavefront issues one instruction per 4 clocks; the chain of a block is 412 of them.
+    chain_floor_ms = max_blocks * 412 * 4 / 2.4e9 * 1e3
+    out["roofline"].update({
+        "alu_peak_GBps": alu_peak, "alu_frac": achieved / alu_peak,
+        "chain_floor_ms": chain_floor_ms, "chain_floor_frac": chain_floor_ms / k_ms,
+        "note": "SHA-1 moves every byte once (HBM traffic = algorithmic bytes) and is bound by the integer "
+                "ALUs when there are many files, by the serial chain of the largest file when there are few"})
+    traffic = measured_traffic(args.workload, args.scale)
+    if traffic is not None:
+        out["roofline"]["traffic"] = traffic
+    if e2e is not None:
+        bw = h2d_bandwidth(torch, device)
+        out["end_to_end"] = {
+            "value": job_bytes / e2e["pinned_seconds"] / GB, "unit": "GB/s",
+            "ms": e2e["pinned_seconds"] * 1e3,
+            "path": "page-locked host memory -> HBM -> kernels -> digests on the host, one snappy_sha1_batch call per GPU",
+            "h2d_pinned_GBps_measured": bw,
+            "copy_only_ms_at_that_rate": total_bytes / bw / GB * 1e3,
+            "digests_match_resident_run": e2e["digests_match_resident_run"]}
+        if "pageable_seconds" in e2e:
+            out["end_to_end"]["pageable_value"] = total_bytes / e2e["pageable_seconds"] / GB
+            out["end_to_end"]["pageable_digests_match"] = e2e["pageable_digests_match"]
+
     if world == 1 and args.workload == "blobs" and args.scale == 1.0 and not args.no_extra:
         out["other_workloads"] = extra_workloads(args, lib, native, torch, device, local_rank)
-
-    if args.e2e:
-        # PCIe-inclusive: the same corpus in ordinary host memory through snappy_sha1_batch.
-        host_all = buf[:total_bytes].cpu().numpy()
-        d2 = np.zeros((n, 20), dtype=np.uint8)
-        times = []
-        for _ in range(2):
-            t0 = time.perf_counter()
-            native.check(lib.snappy_sha1_batch(host_all.ctypes.data, offsets.ctypes.data,
-                                               lengths.ctypes.data, n, d2.ctypes.data), "snappy_sha1_batch")
-            times.append(time.perf_counter() - t0)
-        out["e2e_host_pointers"] = {"value": total_bytes / min(times) / GB, "unit": "GB/s",
-                                    "ms": min(times) * 1e3, "kernel_ms": lib.snappy_profile_last_ms(0),
-                                    "note": "pageable host memory -> HBM -> kernels -> digests, one call",
-                                    "digests_match_resident_run": bool(np.array_equal(d2, digests))}
-        del host_all
 
     if not args.no_cpu_baseline:
         # Bounded sample: the first files of rank 0's corpus up to the sample size.

@@ -69,6 +69,16 @@ const char *snappy_strerror(int code);
 /* Thread-local detail of the last SNAPPY_E_HIP on this thread ("" if none). */
 const char *snappy_last_error_detail(void);
 
+/* Page-locked host memory for file contents.  The reference reads every file
+ * into a managed array (File.ReadAllBytes, Snappy/Core/SnapshotManager.cs:317,
+ * Snappy/Data/SnapshotMigrator.cs:73); a caller that reads into a buffer from
+ * snappy_host_alloc instead lets the entry points below move it to HBM by
+ * direct DMA at PCIe rate, without the staging copy that ordinary (pageable)
+ * memory needs.  Any host pointer is accepted everywhere; this is only faster.
+ * Free with snappy_host_free.  No counterpart in the reference. */
+int snappy_host_alloc(uint64_t bytes, void **out);
+int snappy_host_free(void *ptr);
+
 /* ------------------------------------------------------------------- SHA-1 */
 
 /* Crypto.GetHash without the formatting (Snappy/Utils/Crypto.cs:10-11,

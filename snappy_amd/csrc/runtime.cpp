@@ -254,6 +254,35 @@ extern "C" void snappy_shutdown(void)
 
 extern "C" int snappy_device_count(void) { return device_count(); }
 
+extern "C" int snappy_host_alloc(uint64_t bytes, void **out)
+{
+    if (!out)
+        return SNAPPY_E_INVALID_ARG;
+    *out = nullptr;
+    int st = ensure_initialized();
+    if (st != SNAPPY_OK)
+        return st;
+    if (bytes == 0)
+        return SNAPPY_OK;
+    // Portable: page-locked for every device, whichever one the data ends up on.
+    hipError_t e = hipHostMalloc(out, static_cast<size_t>(bytes), hipHostMallocPortable);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        *out = nullptr;
+        set_error_detail(std::string("hipHostMalloc: ") + hipGetErrorString(e));
+        return SNAPPY_E_NOMEM;
+    }
+    return SNAPPY_OK;
+}
+
+extern "C" int snappy_host_free(void *ptr)
+{
+    if (!ptr)
+        return SNAPPY_OK;
+    SNAPPY_HIP_TRY(hipHostFree(ptr));
+    return SNAPPY_OK;
+}
+
 extern "C" const char *snappy_strerror(int code)
 {
     switch (code) {

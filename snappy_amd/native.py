@@ -39,6 +39,8 @@ SYMBOLS = [
     ("snappy_init", _i, [_i]),
     ("snappy_shutdown", None, []),
     ("snappy_device_count", _i, []),
+    ("snappy_host_alloc", _i, [_u64, ctypes.POINTER(ctypes.c_void_p)]),
+    ("snappy_host_free", _i, [_vp]),
     ("snappy_strerror", ctypes.c_char_p, [_i]),
     ("snappy_last_error_detail", ctypes.c_char_p, []),
     ("snappy_sha1", _i, [_vp, _u64, _vp]),
