@@ -24,6 +24,12 @@ thread_local float t_profile_ms[kProfileKernels] = {-1.f, -1.f};
 int create_slot(Slot &s)
 {
     SNAPPY_HIP_TRY(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+    SNAPPY_HIP_TRY(hipStreamCreateWithFlags(&s.copy_stream, hipStreamNonBlocking));
+    // Uncached on the device, so that a running kernel sees what a copy engine wrote.
+    if (hipExtMallocWithFlags(&s.d_flags, 256, hipDeviceMallocFinegrained) != hipSuccess) {
+        (void)hipGetLastError();
+        s.d_flags = nullptr;  // callers fall back to copy-then-hash
+    }
     for (int k = 0; k < kProfileKernels; ++k)
         for (int j = 0; j < 2; ++j)
             SNAPPY_HIP_TRY(hipEventCreate(&s.ev_prof[k][j]));
@@ -43,6 +49,10 @@ void destroy_slot(Slot &s)
         for (int j = 0; j < 2; ++j)
             if (s.ev_prof[k][j])
                 (void)hipEventDestroy(s.ev_prof[k][j]);
+    if (s.d_flags)
+        (void)hipFree(s.d_flags);
+    if (s.copy_stream)
+        (void)hipStreamDestroy(s.copy_stream);
     if (s.stream)
         (void)hipStreamDestroy(s.stream);
 }

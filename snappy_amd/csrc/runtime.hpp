@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
 #include <condition_variable>
 #include <memory>
 #include <mutex>
@@ -46,6 +47,8 @@ constexpr int kProfileKernels = 2;  // 0 = SHA-1, 1 = LZ4 decode
 // Everything one in-flight call needs on one device.
 struct Slot {
     hipStream_t stream = nullptr;      // main stream of the call
+    hipStream_t copy_stream = nullptr; // host -> device transfers that overlap the kernels
+    void *d_flags = nullptr;           // 256 bytes of fine-grained device memory (progress words)
     hipEvent_t ev_prof[kProfileKernels][2] = {};
     Buffer d_data;     // device arena for host-pointer calls
     Buffer d_tasks;    // Sha1Task[] / chunk tables
@@ -62,6 +65,7 @@ struct DeviceCtx {
     std::mutex mu;
     std::condition_variable cv;
     std::vector<std::unique_ptr<Slot>> slots;
+    std::atomic<bool> overlap_busy{false};  // a kernel that waits for its transfer is running
 };
 
 // RAII lease of a slot; sets the HIP device for the calling thread.

@@ -37,7 +37,7 @@ long env_long(const char *name, long fallback)
 
 int enqueue_sha1_resident(SlotLease &lease, const uint8_t *d_base, const uint64_t *d_offsets,
                           const uint64_t *d_lengths, uint64_t n, uint8_t *d_digests,
-                          hipStream_t stream)
+                          hipStream_t stream, const uint32_t *d_epochs, Sha1Arrival *d_arrival)
 {
     Slot &s = *lease.slot;
     if (n == 0)
@@ -64,12 +64,19 @@ int enqueue_sha1_resident(SlotLease &lease, const uint8_t *d_base, const uint64_
     if (model.forced_path >= kSha1Paths)
         model.forced_path = -1;
     model.forced_waves = static_cast<int>(env_long("SNAPPY_SHA1_WAVES_PER_SIMD", 0));
+    // Waves that wait for a transfer must leave registers free on every SIMD: small
+    // copies are carried out by copy kernels, which would otherwise never be placed
+    // (two of these waves fill a SIMD's register file).
+    if (d_arrival != nullptr)
+        model.forced_waves = 1;
 
     const bool prof = profiling_enabled();
     if (prof)
         SNAPPY_HIP_TRY(hipEventRecord(s.ev_prof[0][0], stream));
-    SNAPPY_HIP_TRY(launch_sha1_plan(d_offsets, d_lengths, n32, d_state, d_tasks, model, stream));
-    SNAPPY_HIP_TRY(launch_sha1_hop(d_base, d_tasks, d_state, d_digests, n32, n_simd, stream));
+    SNAPPY_HIP_TRY(
+        launch_sha1_plan(d_offsets, d_lengths, d_epochs, n32, d_state, d_tasks, model, stream));
+    SNAPPY_HIP_TRY(
+        launch_sha1_hop(d_base, d_tasks, d_state, d_digests, d_arrival, n32, n_simd, stream));
     if (prof)
         SNAPPY_HIP_TRY(hipEventRecord(s.ev_prof[0][1], stream));
     return SNAPPY_OK;
@@ -140,9 +147,173 @@ struct HostRange {
     uint64_t len;
 };
 
+struct Piece {
+    const uint8_t *src;
+    uint64_t dst, len;
+};
+
+// Lays the ranges [first, first + n) out in the device arena in the order
+// `order` (indices relative to first).  Ranges that follow each other both in
+// that order and in host memory keep their relative layout and move as one
+// piece; others are packed at 16-byte aligned offsets.  Returns the arena size.
+uint64_t lay_out(const HostRange *ranges, uint64_t first, const std::vector<uint32_t> &order,
+                 std::vector<uint64_t> &dev_off, std::vector<uint64_t> &lens,
+                 std::vector<Piece> &pieces)
+{
+    uint64_t cursor = 0;
+    for (uint32_t i : order) {
+        const HostRange &r = ranges[first + i];
+        lens[i] = r.len;
+        if (r.len == 0) {
+            dev_off[i] = cursor;
+            continue;
+        }
+        if (!pieces.empty() && pieces.back().src + pieces.back().len == r.ptr &&
+            pieces.back().dst + pieces.back().len == cursor) {
+            dev_off[i] = cursor;
+            pieces.back().len += r.len;
+        } else {
+            cursor = (cursor + 15) & ~uint64_t(15);
+            dev_off[i] = cursor;
+            pieces.push_back({r.ptr, cursor, r.len});
+        }
+        cursor = dev_off[i] + r.len;
+    }
+    return cursor;
+}
+
+// Copy first, then hash: small batches, or no fine-grained memory for the
+// progress words.
+int hash_ranges_serial(SlotLease &lease, const HostRange *ranges, uint64_t first, uint64_t n,
+                       uint8_t *digests)
+{
+    Slot &s = *lease.slot;
+    std::vector<uint64_t> dev_off(n), lens(n);
+    std::vector<uint32_t> order(n);
+    for (uint64_t i = 0; i < n; ++i)
+        order[i] = static_cast<uint32_t>(i);
+    std::vector<Piece> pieces;
+    const uint64_t bytes = lay_out(ranges, first, order, dev_off, lens, pieces);
+    int st;
+    if ((st = s.d_data.ensure(static_cast<size_t>(bytes) + 64)) != SNAPPY_OK)
+        return st;
+    uint8_t *d_base = static_cast<uint8_t *>(s.d_data.ptr);
+    for (const Piece &c : pieces)
+        SNAPPY_HIP_TRY(hipMemcpyAsync(d_base + c.dst, c.src, c.len, hipMemcpyHostToDevice,
+                                      s.stream));
+    return run_sha1_tables(lease, d_base, dev_off.data(), lens.data(), n, digests + 20 * first,
+                           nullptr);
+}
+
+// Hash while copying.  The kernel is launched first; the data then follows on
+// the copy stream, largest files first, in slices of kSliceBytes.  After every
+// slice the copy stream raises the batch's arrival counter (a 4-byte copy of
+// the slice number into uncached device memory), and a wave that has claimed a
+// file waits until the slice holding the file's last byte has landed.  The
+// files whose chains decide the finishing time therefore start within
+// milliseconds, and the rest of the transfer hides behind them.
+int hash_ranges_overlapped(SlotLease &lease, const HostRange *ranges, uint64_t first, uint64_t n,
+                           uint64_t slice_bytes, uint8_t *digests)
+{
+    Slot &s = *lease.slot;
+    std::vector<uint64_t> dev_off(n), lens(n);
+    std::vector<uint32_t> order(n);
+    for (uint64_t i = 0; i < n; ++i)
+        order[i] = static_cast<uint32_t>(i);
+    // Sorting 10^6 tiny files would cost more than their transfer order can win.
+    if (n <= 65536)
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+            return ranges[first + a].len > ranges[first + b].len;
+        });
+    std::vector<Piece> pieces;
+    const uint64_t bytes = lay_out(ranges, first, order, dev_off, lens, pieces);
+    const uint64_t n_slices = (bytes + slice_bytes - 1) / slice_bytes;
+    if (n_slices == 0 || n_slices >= 0x7FFFFFFFull)
+        return hash_ranges_serial(lease, ranges, first, n, digests);
+
+    int st;
+    const size_t table_bytes = n * sizeof(uint64_t);
+    if ((st = s.d_data.ensure(static_cast<size_t>(bytes) + 64)) != SNAPPY_OK) return st;
+    if ((st = s.d_tables.ensure(2 * table_bytes + n * sizeof(uint32_t))) != SNAPPY_OK) return st;
+    if ((st = s.d_out.ensure(n * 20)) != SNAPPY_OK) return st;
+    if ((st = s.h_stage.ensure(n_slices * sizeof(uint32_t))) != SNAPPY_OK) return st;
+    uint8_t *d_base = static_cast<uint8_t *>(s.d_data.ptr);
+    uint64_t *d_off = static_cast<uint64_t *>(s.d_tables.ptr);
+    uint64_t *d_len = d_off + n;
+    uint32_t *d_epochs = reinterpret_cast<uint32_t *>(d_len + n);
+    uint8_t *d_digests = static_cast<uint8_t *>(s.d_out.ptr);
+    Sha1Arrival *d_arrival = static_cast<Sha1Arrival *>(s.d_flags);
+    uint32_t *slice_numbers = static_cast<uint32_t *>(s.h_stage.ptr);
+    for (uint64_t k = 0; k < n_slices; ++k)
+        slice_numbers[k] = static_cast<uint32_t>(k + 1);
+
+    // A file is complete when the slice holding its last byte has landed.
+    std::vector<uint32_t> epochs(n);
+    for (uint64_t i = 0; i < n; ++i)
+        epochs[i] = lens[i] ? static_cast<uint32_t>((dev_off[i] + lens[i] - 1) / slice_bytes + 1) : 0u;
+
+    const Sha1Arrival zero = {0, 0, 0, 0};
+    SNAPPY_HIP_TRY(hipMemcpy(d_arrival, &zero, sizeof(zero), hipMemcpyHostToDevice));
+    SNAPPY_HIP_TRY(hipMemcpyAsync(d_off, dev_off.data(), table_bytes, hipMemcpyHostToDevice, s.stream));
+    SNAPPY_HIP_TRY(hipMemcpyAsync(d_len, lens.data(), table_bytes, hipMemcpyHostToDevice, s.stream));
+    SNAPPY_HIP_TRY(hipMemcpyAsync(d_epochs, epochs.data(), n * sizeof(uint32_t),
+                                  hipMemcpyHostToDevice, s.stream));
+    st = enqueue_sha1_resident(lease, d_base, d_off, d_len, n, d_digests, s.stream, d_epochs,
+                               d_arrival);
+    if (st != SNAPPY_OK)
+        return st;  // nothing was launched that waits
+
+    // From here on a kernel may be waiting: whatever goes wrong, it has to be told.
+    hipError_t copy_error = hipSuccess;
+    uint64_t next_mark = 1;  // slice whose end has not been marked yet
+    for (const Piece &c : pieces) {
+        uint64_t done = 0;
+        while (done < c.len && copy_error == hipSuccess) {
+            const uint64_t pos = c.dst + done;
+            const uint64_t slice_end = (pos / slice_bytes + 1) * slice_bytes;
+            const uint64_t take = std::min<uint64_t>(c.len - done, slice_end - pos);
+            copy_error = hipMemcpyAsync(d_base + pos, c.src + done, take, hipMemcpyHostToDevice,
+                                        s.copy_stream);
+            done += take;
+            // Every slice that ends at or before this position is complete.
+            const uint64_t complete = (c.dst + done) / slice_bytes;
+            while (copy_error == hipSuccess && next_mark <= complete) {
+                copy_error = hipMemcpyAsync(&d_arrival->arrived, &slice_numbers[next_mark - 1],
+                                            sizeof(uint32_t), hipMemcpyHostToDevice, s.copy_stream);
+                ++next_mark;
+            }
+        }
+        if (copy_error != hipSuccess)
+            break;
+    }
+    if (copy_error == hipSuccess)  // the last, partial slice (and any gap slices before it)
+        copy_error = hipMemcpyAsync(&d_arrival->arrived, &slice_numbers[n_slices - 1],
+                                    sizeof(uint32_t), hipMemcpyHostToDevice, s.copy_stream);
+    if (copy_error == hipSuccess)
+        copy_error = hipStreamSynchronize(s.copy_stream);
+    if (copy_error != hipSuccess) {
+        set_error_detail(std::string("host to device transfer: ") + hipGetErrorString(copy_error));
+        (void)hipGetLastError();
+        const uint32_t one = 1;
+        (void)hipMemcpy(&d_arrival->abort, &one, sizeof(one), hipMemcpyHostToDevice);
+        (void)hipStreamSynchronize(s.stream);  // the kernel leaves on abort (or on its own time limit)
+        return SNAPPY_E_HIP;
+    }
+    SNAPPY_HIP_TRY(hipMemcpyAsync(digests + 20 * first, d_digests, n * 20, hipMemcpyDeviceToHost,
+                                  s.stream));
+    SNAPPY_HIP_TRY(hipStreamSynchronize(s.stream));
+    Sha1Arrival seen;
+    SNAPPY_HIP_TRY(hipMemcpy(&seen, d_arrival, sizeof(seen), hipMemcpyDeviceToHost));
+    if (seen.error) {
+        set_error_detail("SHA-1 kernel gave up waiting for its input");
+        return SNAPPY_E_HIP;
+    }
+    finish_sha1_profile(lease);
+    return SNAPPY_OK;
+}
+
 // Copies the ranges [first, last) into the slot's device arena and hashes them
-// on the slot's device.  Ranges that touch in host memory are moved by one copy
-// and keep their relative layout; others are packed at 16-byte aligned offsets.
+// on the slot's device.
 int hash_ranges_on_device(int device, const HostRange *ranges, uint64_t first, uint64_t last,
                           uint8_t *digests)
 {
@@ -150,41 +321,26 @@ int hash_ranges_on_device(int device, const HostRange *ranges, uint64_t first, u
     int st = lease.acquire(device);
     if (st != SNAPPY_OK)
         return st;
-    Slot &s = *lease.slot;
     const uint64_t n = last - first;
-
-    std::vector<uint64_t> dev_off(n), lens(n);
-    struct Copy {
-        const uint8_t *src;
-        uint64_t dst, len;
-    };
-    std::vector<Copy> copies;
-    uint64_t cursor = 0;
-    for (uint64_t i = 0; i < n; ++i) {
-        const HostRange &r = ranges[first + i];
-        lens[i] = r.len;
-        if (r.len == 0) {
-            dev_off[i] = cursor;
-            continue;
-        }
-        if (!copies.empty() && copies.back().src + copies.back().len == r.ptr) {
-            dev_off[i] = copies.back().dst + copies.back().len;
-            copies.back().len += r.len;
-        } else {
-            cursor = (cursor + 15) & ~uint64_t(15);
-            dev_off[i] = cursor;
-            copies.push_back({r.ptr, cursor, r.len});
-        }
-        cursor = dev_off[i] + r.len;
-    }
-    if ((st = s.d_data.ensure(static_cast<size_t>(cursor) + 64)) != SNAPPY_OK)
-        return st;
-    uint8_t *d_base = static_cast<uint8_t *>(s.d_data.ptr);
-    for (const Copy &c : copies)
-        SNAPPY_HIP_TRY(hipMemcpyAsync(d_base + c.dst, c.src, c.len, hipMemcpyHostToDevice,
-                                      s.stream));
-    return run_sha1_tables(lease, d_base, dev_off.data(), lens.data(), n, digests + 20 * first,
-                           nullptr);
+    uint64_t total = 0;
+    for (uint64_t i = 0; i < n; ++i)
+        total += ranges[first + i].len;
+    // SNAPPY_OVERLAP_MIN_BYTES / SNAPPY_OVERLAP_SLICE_BYTES: tests and tuning.
+    const uint64_t min_bytes =
+        static_cast<uint64_t>(env_long("SNAPPY_OVERLAP_MIN_BYTES", 64L << 20));
+    // Slices end on 256-byte boundaries, so no cache line holds bytes of two slices: a
+    // line is first read only after everything in it has landed.
+    const uint64_t slice = std::max<uint64_t>(
+        256, static_cast<uint64_t>(env_long("SNAPPY_OVERLAP_SLICE_BYTES", 32L << 20)) & ~uint64_t(255));
+    if (lease.slot->d_flags == nullptr || total < min_bytes)
+        return hash_ranges_serial(lease, ranges, first, n, digests);
+    // One waiting kernel per device at a time, for the same reason: a second
+    // caller copies first and hashes afterwards.
+    if (lease.dev->overlap_busy.exchange(true))
+        return hash_ranges_serial(lease, ranges, first, n, digests);
+    st = hash_ranges_overlapped(lease, ranges, first, n, slice, digests);
+    lease.dev->overlap_busy.store(false);
+    return st;
 }
 
 }  // namespace

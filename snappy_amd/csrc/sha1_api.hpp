@@ -12,9 +12,12 @@ namespace snappy {
 // Plans and launches the SHA-1 kernels for n messages whose (offset, length)
 // tables and data are all in device memory; digests (20 bytes per message, in
 // the caller's message order) are written to d_digests.  Enqueues only.
+// d_epochs / d_arrival (both null, or both set): the data is still being copied
+// to the device; message i is complete once d_arrival->arrived >= d_epochs[i].
 int enqueue_sha1_resident(SlotLease &lease, const uint8_t *d_base, const uint64_t *d_offsets,
                           const uint64_t *d_lengths, uint64_t n, uint8_t *d_digests,
-                          hipStream_t stream);
+                          hipStream_t stream, const uint32_t *d_epochs = nullptr,
+                          Sha1Arrival *d_arrival = nullptr);
 
 // After the stream has been synchronised: stores the kernels' event time for
 // snappy_profile_last_ms(0).

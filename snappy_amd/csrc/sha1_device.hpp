@@ -15,12 +15,14 @@
 namespace snappy {
 
 // One message to hash: bytes [offset, offset+len) of the batch's base pointer;
-// the digest goes to digests + 20*out_index.
+// the digest goes to digests + 20*out_index.  ready_epoch != 0: the bytes are
+// still on their way from the host and are complete once the batch's arrival
+// counter has reached this value.
 struct Sha1Task {
     uint64_t offset;
     uint64_t len;
     uint32_t out_index;
-    uint32_t reserved;
+    uint32_t ready_epoch;
 };
 
 constexpr uint32_t kSha1Init[5] = {0x67452301u, 0xEFCDAB89u, 0x98BADCFEu, 0x10325476u,

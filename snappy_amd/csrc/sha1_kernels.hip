@@ -54,13 +54,50 @@ __device__ __forceinline__ uint32_t rotate_in_group(uint32_t v)
         return v;
 }
 
+// Waits until the transfer of the batch has passed slice `need` (per lane; 0 =
+// nothing to wait for).  Returns false when the wave should give up: the host
+// raised `abort`, another wave reported an error, or nothing arrived for ~10 s.
+// The words are in uncached memory; one coalesced load per poll, ~50 us apart.
+constexpr uint32_t kMaxArrivalPolls = 200000;
+
+__device__ __forceinline__ bool wait_for_arrival(Sha1Arrival *arrival, uint32_t need)
+{
+    if (arrival == nullptr || __ballot(need != 0) == 0)
+        return true;
+    uint32_t last_seen = 0, idle_polls = 0;
+    for (;;) {
+        const uint32_t seen = __builtin_amdgcn_readfirstlane(
+            __hip_atomic_load(&arrival->arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+        if (__ballot(seen < need) == 0) {
+            // Order the message loads after the observation of the counter.
+            __atomic_thread_fence(__ATOMIC_ACQUIRE);
+            return true;
+        }
+        const uint32_t stop = __builtin_amdgcn_readfirstlane(
+            __hip_atomic_load(&arrival->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) |
+            __hip_atomic_load(&arrival->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+        idle_polls = (seen != last_seen) ? 0u : idle_polls + 1u;
+        last_seen = seen;
+        if (stop != 0 || idle_polls > kMaxArrivalPolls) {
+            __hip_atomic_store(&arrival->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            return false;
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+            __builtin_amdgcn_s_sleep(127);
+    }
+}
+
+enum HopResult { kHopEmpty = 0, kHopDone = 1, kHopGiveUp = 2 };
+
 // Claims the next 64 / G messages of tasks [first, end) and hashes them, one per
-// group.  Returns false when the range was already exhausted.
+// group.  kHopEmpty: the range was already exhausted.
 template <int G>
-__device__ __forceinline__ bool hop_once(const uint8_t *__restrict__ base,
-                                         const Sha1Task *__restrict__ tasks, uint32_t first,
-                                         uint32_t end, uint32_t *queue,
-                                         uint8_t *__restrict__ digests, uint32_t lane)
+__device__ __forceinline__ HopResult hop_once(const uint8_t *__restrict__ base,
+                                              const Sha1Task *__restrict__ tasks, uint32_t first,
+                                              uint32_t end, uint32_t *queue,
+                                              uint8_t *__restrict__ digests,
+                                              Sha1Arrival *arrival, uint32_t lane)
 {
     constexpr uint32_t kGroups = kWave / G;
     // With one lane per message a superblock is a single block, too short to cover
@@ -71,10 +108,12 @@ __device__ __forceinline__ bool hop_once(const uint8_t *__restrict__ base,
 
     const uint32_t i0 = first + wave_claim(queue, kGroups, lane);
     if (i0 >= end)
-        return false;
+        return kHopEmpty;
     // Groups past the end of the range idle through this round (no blocks).
     const bool have = (G == 64) || i0 + grp < end;
     const Sha1Task task = tasks[have ? i0 + grp : i0];
+    if (!wait_for_arrival(arrival, have ? task.ready_epoch : 0u))
+        return kHopGiveUp;
     const uint8_t *msg = base + task.offset;
     const uint64_t len = have ? task.len : 0;
     const uint64_t n_full = len >> 6;
@@ -171,7 +210,7 @@ __device__ __forceinline__ bool hop_once(const uint8_t *__restrict__ base,
     // After n_blocks hops the state sits in lane (n_blocks mod G) of the group.
     if (have && j == static_cast<uint32_t>(n_blocks & (G - 1)))
         store_digest(digests + 20ull * task.out_index, h);
-    return true;
+    return kHopDone;
 }
 
 // Every wave repeatedly takes the most urgent piece of work left: among the four
@@ -182,7 +221,8 @@ __device__ __forceinline__ bool hop_once(const uint8_t *__restrict__ base,
 // total SIMD time / SIMDs).
 __global__ void __launch_bounds__(kWave)
 sha1_hop_kernel(const uint8_t *__restrict__ base, const Sha1Task *__restrict__ tasks,
-                Sha1PlanState *__restrict__ state, uint8_t *__restrict__ digests)
+                Sha1PlanState *__restrict__ state, uint8_t *__restrict__ digests,
+                Sha1Arrival *arrival)
 {
     const uint32_t lane = lane_id();
     if (blockIdx.x >= gridDim.x / kMaxWavesPerSimd *
@@ -221,26 +261,30 @@ sha1_hop_kernel(const uint8_t *__restrict__ base, const Sha1Task *__restrict__ t
         if (best < 0)
             break;
         // A failed claim only means another wave was quicker: look again.
+        HopResult r;
         switch (best) {
-        case 0: hop_once<64>(base, tasks, lo[0], hi[0], &state->queue[0].next, digests, lane); break;
-        case 1: hop_once<16>(base, tasks, lo[1], hi[1], &state->queue[1].next, digests, lane); break;
-        case 2: hop_once<4>(base, tasks, lo[2], hi[2], &state->queue[2].next, digests, lane); break;
-        default: hop_once<1>(base, tasks, lo[3], hi[3], &state->queue[3].next, digests, lane); break;
+        case 0: r = hop_once<64>(base, tasks, lo[0], hi[0], &state->queue[0].next, digests, arrival, lane); break;
+        case 1: r = hop_once<16>(base, tasks, lo[1], hi[1], &state->queue[1].next, digests, arrival, lane); break;
+        case 2: r = hop_once<4>(base, tasks, lo[2], hi[2], &state->queue[2].next, digests, arrival, lane); break;
+        default: r = hop_once<1>(base, tasks, lo[3], hi[3], &state->queue[3].next, digests, arrival, lane); break;
         }
+        if (r == kHopGiveUp)
+            break;
     }
 }
 
 }  // namespace
 
 hipError_t launch_sha1_hop(const uint8_t *d_base, const Sha1Task *d_tasks, Sha1PlanState *d_state,
-                           uint8_t *d_digests, uint32_t n, uint32_t n_simd, hipStream_t stream)
+                           uint8_t *d_digests, Sha1Arrival *d_arrival, uint32_t n, uint32_t n_simd,
+                           hipStream_t stream)
 {
     if (n == 0)
         return hipSuccess;
     // A multiple of kMaxWavesPerSimd, so that the kernel's cut-off is exact.
     const uint32_t per = n < n_simd ? n : n_simd;
     hipLaunchKernelGGL(sha1_hop_kernel, dim3(per * kMaxWavesPerSimd), dim3(kWave), 0, stream,
-                       d_base, d_tasks, d_state, d_digests);
+                       d_base, d_tasks, d_state, d_digests, d_arrival);
     return hipGetLastError();
 }
 

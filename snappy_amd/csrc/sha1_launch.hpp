@@ -49,18 +49,31 @@ struct Sha1PlanState {
     unsigned long long blocks[kPlanBuckets];  // padded blocks per bucket
 };
 
+// Progress words of a batch whose data is copied to the device while the kernel
+// already runs.  They live in fine-grained (uncached) device memory: the copy
+// stream raises `arrived` after every slice of the transfer, the kernel's waves
+// poll it before they touch a message.
+struct Sha1Arrival {
+    uint32_t arrived;  // slices of the transfer that have landed
+    uint32_t abort;    // host: the transfer failed, give up
+    uint32_t error;    // kernel: gave up (abort seen, or no progress for ~10 s)
+    uint32_t reserved;
+};
+
 // Sorts the n messages by descending padded size into d_tasks and cuts the
-// sorted list into the paths' ranges (see sha1_plan.hip).
-hipError_t launch_sha1_plan(const uint64_t *d_offsets, const uint64_t *d_lengths, uint32_t n,
-                            Sha1PlanState *d_state, Sha1Task *d_tasks, const Sha1CostModel &model,
-                            hipStream_t stream);
+// sorted list into the paths' ranges (see sha1_plan.hip).  d_epochs (may be
+// null) gives each message's Sha1Task::ready_epoch.
+hipError_t launch_sha1_plan(const uint64_t *d_offsets, const uint64_t *d_lengths,
+                            const uint32_t *d_epochs, uint32_t n, Sha1PlanState *d_state,
+                            Sha1Task *d_tasks, const Sha1CostModel &model, hipStream_t stream);
 
 // Hashes the planned batch.  n_simd * kMaxWavesPerSimd single-wave workgroups are
 // launched (fewer for small batches); those beyond the planner's waves_per_simd
 // leave at once, the others take work, longest chains first, until none is left.
 constexpr int kMaxWavesPerSimd = 2;
+// d_arrival (may be null): see Sha1Arrival.
 hipError_t launch_sha1_hop(const uint8_t *d_base, const Sha1Task *d_tasks,
-                           Sha1PlanState *d_state, uint8_t *d_digests, uint32_t n,
-                           uint32_t n_simd, hipStream_t stream);
+                           Sha1PlanState *d_state, uint8_t *d_digests, Sha1Arrival *d_arrival,
+                           uint32_t n, uint32_t n_simd, hipStream_t stream);
 
 }  // namespace snappy

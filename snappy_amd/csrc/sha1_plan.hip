@@ -197,8 +197,9 @@ plan_scan(Sha1PlanState *__restrict__ st, uint32_t n, Sha1CostModel m)
 // per bucket in LDS, reserves its ranges with one global atomic per bucket, then
 // places its files.
 __global__ void __launch_bounds__(kPlanThreads)
-plan_scatter(const uint64_t *__restrict__ offsets, const uint64_t *__restrict__ lengths, uint32_t n,
-             Sha1PlanState *__restrict__ st, Sha1Task *__restrict__ tasks)
+plan_scatter(const uint64_t *__restrict__ offsets, const uint64_t *__restrict__ lengths,
+             const uint32_t *__restrict__ epochs, uint32_t n, Sha1PlanState *__restrict__ st,
+             Sha1Task *__restrict__ tasks)
 {
     __shared__ uint32_t local[kPlanBuckets];
     __shared__ uint32_t base_of[kPlanBuckets];
@@ -229,7 +230,7 @@ plan_scatter(const uint64_t *__restrict__ offsets, const uint64_t *__restrict__ 
             t.offset = offsets[i];
             t.len = lengths[i];
             t.out_index = i;
-            t.reserved = 0;
+            t.ready_epoch = epochs ? epochs[i] : 0u;
             tasks[base_of[bucket[j]] + slot[j]] = t;
         }
     }
@@ -237,9 +238,9 @@ plan_scatter(const uint64_t *__restrict__ offsets, const uint64_t *__restrict__ 
 
 }  // namespace
 
-hipError_t launch_sha1_plan(const uint64_t *d_offsets, const uint64_t *d_lengths, uint32_t n,
-                            Sha1PlanState *d_state, Sha1Task *d_tasks, const Sha1CostModel &model,
-                            hipStream_t stream)
+hipError_t launch_sha1_plan(const uint64_t *d_offsets, const uint64_t *d_lengths,
+                            const uint32_t *d_epochs, uint32_t n, Sha1PlanState *d_state,
+                            Sha1Task *d_tasks, const Sha1CostModel &model, hipStream_t stream)
 {
     if (n == 0)
         return hipSuccess;
@@ -252,7 +253,7 @@ hipError_t launch_sha1_plan(const uint64_t *d_offsets, const uint64_t *d_lengths
                        d_state);
     hipLaunchKernelGGL(plan_scan, dim3(1), dim3(kPlanBuckets), 0, stream, d_state, n, model);
     hipLaunchKernelGGL(plan_scatter, dim3(groups), dim3(kPlanThreads), 0, stream, d_offsets,
-                       d_lengths, n, d_state, d_tasks);
+                       d_lengths, d_epochs, n, d_state, d_tasks);
     return hipGetLastError();
 }
 

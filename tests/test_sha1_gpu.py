@@ -24,7 +24,7 @@ def force_path(path):
 
 @pytest.fixture(autouse=True)
 def _clean_env():
-    keep = {k: os.environ.get(k) for k in (FORCE,)}
+    keep = {k: os.environ.get(k) for k in (FORCE, "SNAPPY_OVERLAP_MIN_BYTES", "SNAPPY_OVERLAP_SLICE_BYTES")}
     yield
     for k, v in keep.items():
         if v is None:
@@ -223,3 +223,31 @@ def test_ragged_groups_and_partial_waves(snappy, oracle):
         for path in ALL_PATHS + (None,):
             force_path(path)
             assert np.array_equal(snappy.sha1_batch(base, offsets, lengths), want), (n, path)
+
+
+@pytest.mark.parametrize("slice_bytes", ["4096", "1048576"])
+def test_hash_while_copying(snappy, oracle, slice_bytes):
+    """The host-pointer entry points start the kernel before the data has arrived and feed it
+    slice by slice.  Forced on for small batches here, with slices far smaller than the files;
+    the second and third calls reuse the same device arena with different bytes (a stale cache
+    line would show up as a wrong digest)."""
+    os.environ["SNAPPY_OVERLAP_MIN_BYTES"] = "0"
+    os.environ["SNAPPY_OVERLAP_SLICE_BYTES"] = slice_bytes
+    rng = np.random.default_rng(61)
+    sizes = np.concatenate([rng.integers(0, 3000, size=300), rng.integers(10_000, 400_000, size=40),
+                            np.array([0, 1, 63, 64, 2_000_003])]).astype(np.uint64)
+    rng.shuffle(sizes)
+    offsets = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.uint64)
+    for rep in range(3):
+        base = rng.integers(0, 256, size=int(sizes.sum()) + 1, dtype=np.uint8)
+        want = oracle.sha1_batch_np(base, offsets, sizes)
+        assert np.array_equal(snappy.sha1_batch(base, offsets, sizes), want), rep
+    blobs = [H.random_bytes(int(n), 7000 + i) for i, n in enumerate(sizes[:60])]
+    got = snappy.sha1_files(blobs)
+    for i, b in enumerate(blobs):
+        assert got[i].tobytes() == oracle.sha1(b), i
+    for path in ALL_PATHS:
+        force_path(path)
+        base = rng.integers(0, 256, size=int(sizes.sum()) + 1, dtype=np.uint8)
+        assert np.array_equal(snappy.sha1_batch(base, offsets, sizes),
+                              oracle.sha1_batch_np(base, offsets, sizes)), path
