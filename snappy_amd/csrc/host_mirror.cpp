@@ -11,6 +11,11 @@
 //
 // All hashing and decoding goes through the same GPU entry points as the rest of
 // the library; this file only moves bytes between the file system and them.
+#include <fcntl.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstring>
@@ -18,8 +23,10 @@
 #include <filesystem>
 #include <fstream>
 #include <map>
+#include <mutex>
 #include <string>
 #include <system_error>
+#include <thread>
 #include <vector>
 
 #include "../../include/snappyhash.h"
@@ -191,59 +198,198 @@ void hex40(const uint8_t *digest, char *out41)
 
 using namespace snappy;
 
+namespace snappy {
+namespace {
+
+// Process-wide page-locked arena for file contents on their way to the GPU
+// (grow-only; a second concurrent caller gets a temporary one of its own).
+struct FileArena {
+    std::mutex mu;
+    bool busy = false;
+    void *ptr = nullptr;
+    uint64_t cap = 0;
+};
+FileArena g_file_arena;
+
+class ArenaLease {
+public:
+    ~ArenaLease()
+    {
+        if (shared_) {
+            std::lock_guard<std::mutex> lk(g_file_arena.mu);
+            g_file_arena.busy = false;
+        } else if (ptr_) {
+            (void)snappy_host_free(ptr_);
+        }
+    }
+    int acquire(uint64_t bytes)
+    {
+        {
+            std::lock_guard<std::mutex> lk(g_file_arena.mu);
+            if (!g_file_arena.busy) {
+                if (g_file_arena.cap < bytes) {
+                    if (g_file_arena.ptr)
+                        (void)snappy_host_free(g_file_arena.ptr);
+                    g_file_arena.ptr = nullptr;
+                    g_file_arena.cap = 0;
+                    const uint64_t want = bytes + bytes / 4;
+                    int st = snappy_host_alloc(want, &g_file_arena.ptr);
+                    if (st != SNAPPY_OK)
+                        return st;
+                    g_file_arena.cap = want;
+                }
+                g_file_arena.busy = true;
+                shared_ = true;
+                ptr_ = g_file_arena.ptr;
+                return SNAPPY_OK;
+            }
+        }
+        return snappy_host_alloc(bytes, &ptr_);
+    }
+    uint8_t *data() const { return static_cast<uint8_t *>(ptr_); }
+
+private:
+    void *ptr_ = nullptr;
+    bool shared_ = false;
+};
+
+// Runs fn(k) for k in [0, n) on up to kIoThreads threads (file reads and writes
+// are latency-bound, so several are kept in flight).
+constexpr unsigned kIoThreads = 8;
+
+template <typename Fn>
+void parallel_for(uint64_t n, Fn fn)
+{
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const unsigned threads = static_cast<unsigned>(std::min<uint64_t>(n, std::min(hw, kIoThreads)));
+    if (threads <= 1) {
+        for (uint64_t k = 0; k < n; ++k)
+            fn(k);
+        return;
+    }
+    std::atomic<uint64_t> next{0};
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < threads; ++t)
+        pool.emplace_back([&] {
+            for (uint64_t k = next.fetch_add(1); k < n; k = next.fetch_add(1))
+                fn(k);
+        });
+    for (auto &t : pool)
+        t.join();
+}
+
+// Reads exactly `size` bytes of the file into dst; false if it is shorter or unreadable.
+bool read_exact(const char *path, uint8_t *dst, uint64_t size)
+{
+    const int fd = ::open(path, O_RDONLY | O_CLOEXEC);
+    if (fd < 0)
+        return false;
+    uint64_t done = 0;
+    while (done < size) {
+        const ssize_t r = ::pread(fd, dst + done, static_cast<size_t>(std::min<uint64_t>(size - done, 1u << 30)),
+                                  static_cast<off_t>(done));
+        if (r <= 0)
+            break;
+        done += static_cast<uint64_t>(r);
+    }
+    // A file that grew since it was measured is read to its new end by ReadAllBytes;
+    // keep it simple and exact: such a file is reported as unreadable.
+    uint8_t probe;
+    const bool grew = done == size && ::pread(fd, &probe, 1, static_cast<off_t>(size)) == 1;
+    ::close(fd);
+    return done == size && !grew;
+}
+
+}  // namespace
+}  // namespace snappy
+
+// The hash-and-store loop with the file system taken off the critical path: the
+// sources are read by several threads straight into page-locked memory, hashed
+// in one batch whose transfer overlaps the kernel, and the new <HASH>.dat files
+// are written by several threads.  Per entry the outcome is what the reference's
+// sequential loop produces.
 extern "C" int snappy_store_files(const char *const *paths, uint64_t n, const char *files_dir,
                                   char *hex, uint8_t *status)
 {
     if (n && (!paths || !hex || !status))
         return SNAPPY_E_INVALID_ARG;
-    // File.Exists + File.ReadAllBytes per entry (SnapshotManager.cs:314-317).
-    std::vector<std::vector<uint8_t>> blobs;
-    std::vector<uint64_t> owner;
-    blobs.reserve(n);
+    // File.Exists per entry (SnapshotManager.cs:314-315): missing sources are skipped.
+    std::vector<uint64_t> owner, sizes, offs;
+    uint64_t total = 0;
     for (uint64_t i = 0; i < n; ++i) {
         hex[41 * i] = '\0';
-        status[i] = 1;  // source missing: `continue`
+        status[i] = 1;
         if (!paths[i])
             continue;
         std::error_code ec;
         if (!fs::is_regular_file(paths[i], ec))
             continue;
-        std::vector<uint8_t> bytes;
-        if (!read_all_bytes(paths[i], bytes))
+        const uint64_t size = static_cast<uint64_t>(fs::file_size(paths[i], ec));
+        if (ec)
             continue;
-        blobs.push_back(std::move(bytes));
         owner.push_back(i);
-        status[i] = 0;
+        sizes.push_back(size);
+        offs.push_back(total);
+        total = (total + size + 255) & ~uint64_t(255);
     }
-    if (blobs.empty())
+    if (owner.empty())
         return SNAPPY_OK;
-    // Crypto.GetHash for all of them in one GPU batch (:318).
-    std::vector<const uint8_t *> ptrs(blobs.size());
-    std::vector<uint64_t> lens(blobs.size());
-    for (size_t k = 0; k < blobs.size(); ++k) {
-        ptrs[k] = blobs[k].empty() ? nullptr : blobs[k].data();
-        lens[k] = blobs[k].size();
-    }
-    std::vector<uint8_t> digests(blobs.size() * 20);
-    int st = snappy_sha1_files(ptrs.data(), lens.data(), blobs.size(), digests.data());
+    ArenaLease arena;
+    int st = arena.acquire(total + 256);
     if (st != SNAPPY_OK)
         return st;
-    if (files_dir) {
-        std::error_code ec;
-        fs::create_directories(files_dir, ec);
-    }
-    for (size_t k = 0; k < blobs.size(); ++k) {
-        char *h = hex + 41 * owner[k];
-        hex40(digests.data() + 20 * k, h);
-        if (!files_dir)
-            continue;
-        // `if (!File.Exists(hashedFilePath)) File.Copy(...)` (:457-466).
-        const std::string target = (fs::path(files_dir) / (std::string(h) + ".dat")).string();
-        std::error_code ec;
-        if (!fs::exists(target, ec) && !write_all_bytes(target, blobs[k].data(), blobs[k].size())) {
-            set_error_detail("cannot write " + target);
-            return SNAPPY_E_INVALID_ARG;
+    // File.ReadAllBytes (:317), many files in flight.
+    std::vector<uint8_t> readable(owner.size(), 0);
+    parallel_for(owner.size(), [&](uint64_t k) {
+        readable[k] = read_exact(paths[owner[k]], arena.data() + offs[k], sizes[k]) ? 1 : 0;
+    });
+    std::vector<uint64_t> b_off, b_len, b_owner;
+    for (size_t k = 0; k < owner.size(); ++k)
+        if (readable[k]) {
+            b_off.push_back(offs[k]);
+            b_len.push_back(sizes[k]);
+            b_owner.push_back(owner[k]);
+            status[owner[k]] = 0;
         }
+    if (b_owner.empty())
+        return SNAPPY_OK;
+    // Crypto.GetHash for all of them in one GPU batch (:318).
+    std::vector<uint8_t> digests(b_owner.size() * 20);
+    st = snappy_sha1_batch(arena.data(), b_off.data(), b_len.data(), b_owner.size(), digests.data());
+    if (st != SNAPPY_OK)
+        return st;
+    // `if (!File.Exists(hashedFilePath)) File.Copy(...)` (:457-466).  Entries with the
+    // same digest have the same bytes: the first of them writes the file.
+    std::map<std::string, size_t> first_with_hash;
+    std::vector<size_t> writers;
+    for (size_t k = 0; k < b_owner.size(); ++k) {
+        char *h = hex + 41 * b_owner[k];
+        hex40(digests.data() + 20 * k, h);
+        if (files_dir && first_with_hash.emplace(std::string(h), k).second)
+            writers.push_back(k);
+    }
+    if (!files_dir)
+        return SNAPPY_OK;
+    std::error_code ec;
+    fs::create_directories(files_dir, ec);
+    std::atomic<bool> write_failed{false};
+    std::mutex fail_mu;
+    std::string failed_target;
+    parallel_for(writers.size(), [&](uint64_t w) {
+        const size_t k = writers[w];
+        const std::string target =
+            (fs::path(files_dir) / (std::string(hex + 41 * b_owner[k]) + ".dat")).string();
+        std::error_code e2;
+        if (!fs::exists(target, e2) &&
+            !write_all_bytes(target, arena.data() + b_off[k], static_cast<size_t>(b_len[k]))) {
+            write_failed.store(true);
+            std::lock_guard<std::mutex> lk(fail_mu);
+            failed_target = target;
+        }
+    });
+    if (write_failed.load()) {
+        set_error_detail("cannot write " + failed_target);
+        return SNAPPY_E_INVALID_ARG;
     }
     return SNAPPY_OK;
 }

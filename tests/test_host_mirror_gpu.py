@@ -42,6 +42,31 @@ def test_store_files_dedups_by_digest(snappy, oracle, tmp_path):
     assert snappy.store_files(paths[:2]) == want[:2]
 
 
+def test_store_files_many_files_parallel_reader(snappy, oracle, tmp_path, monkeypatch):
+    """A folder's worth of files through the multi-threaded reader and writer, with the
+    hash-while-copying transfer forced on; every stored file must carry its own SHA-1 as name."""
+    monkeypatch.setenv("SNAPPY_OVERLAP_MIN_BYTES", "0")
+    monkeypatch.setenv("SNAPPY_OVERLAP_SLICE_BYTES", "65536")
+    rng = np.random.default_rng(77)
+    src = tmp_path / "mods"
+    src.mkdir()
+    sizes = np.concatenate([rng.integers(0, 5000, size=200), rng.integers(50_000, 900_000, size=40),
+                            np.array([3_000_001, 0, 64])])
+    paths, want = [], []
+    for i, n in enumerate(sizes):
+        b = H.random_bytes(int(n), 9000 + i % 230)      # some contents repeat
+        p = src / f"f{i:04d}.mdl"
+        p.write_bytes(b)
+        paths.append(str(p))
+        want.append(hashlib.sha1(b).hexdigest().upper())
+    files_dir = tmp_path / "_files"
+    assert snappy.store_files(paths, str(files_dir)) == want
+    stored = sorted(os.listdir(files_dir))
+    assert stored == sorted({h + ".dat" for h in want})
+    for name in stored[::7]:
+        assert hashlib.sha1((files_dir / name).read_bytes()).hexdigest().upper() + ".dat" == name
+
+
 def test_import_mcdf_writes_reference_layout(snappy, oracle, tmp_path):
     rng = np.random.default_rng(5)
     files = []
