@@ -74,6 +74,42 @@ def make_sizes(workload: str, rng: np.random.Generator, scale: float):
     raise SystemExit(f"unknown workload {workload}")
 
 
+def rank_corpus(args, rank, world, cut_fn):
+    """File sizes this rank hashes.  Weak scaling (default): every rank draws its own corpus of
+    the configured shape.  --strong: one corpus for the whole job, the same on every rank,
+    sharded by file into contiguous groups of near-equal byte count (cut_fn = the library's
+    snappy_plan_shards, or its host restatement in the dry run); rank r takes group r."""
+    if not args.strong or world == 1:
+        return make_sizes(args.workload, np.random.default_rng(0x534E4150 + rank), args.scale)
+    lengths = make_sizes(args.workload, np.random.default_rng(0x534E4150), args.scale)
+    cuts = cut_fn(lengths, world)
+    return lengths[int(cuts[rank]): int(cuts[rank + 1])]
+
+
+def shard_cuts(lib, lengths, k):
+    cuts = np.zeros(k + 1, dtype=np.uint64)
+    ln = np.ascontiguousarray(lengths, dtype=np.uint64)
+    if lib.snappy_plan_shards(ln.ctypes.data, len(ln), k, cuts.ctypes.data) != 0:
+        raise SystemExit("snappy_plan_shards failed")
+    return cuts
+
+
+def host_shard_cuts(lengths, k):
+    """snappy_plan_shards restated: cut j is the first file index at which the running byte
+    count reaches j/k of the total."""
+    total = int(lengths.sum())
+    cuts = [0]
+    acc, j = 0, 1
+    for i, n in enumerate(lengths):
+        acc += int(n)
+        while j < k and acc * k >= total * j:
+            cuts.append(i + 1)
+            j += 1
+    while len(cuts) < k + 1:
+        cuts.append(len(lengths))
+    return np.array(cuts, dtype=np.uint64)
+
+
 def fill_random(torch, n_bytes: int, device, seed: int):
     """Random bytes resident in HBM (SHA-1 timing does not depend on content)."""
     g = torch.Generator(device=device)
@@ -420,8 +456,10 @@ def dry_run(args, rank, world):
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", rank=rank, world_size=world)
-    rng = np.random.default_rng(0x534E4150 + rank)
-    lengths = make_sizes(args.workload if args.workload != "mcdf" else "folder", rng, 2e-3 * args.scale)
+    small = argparse.Namespace(**vars(args))
+    small.workload = args.workload if args.workload != "mcdf" else "folder"
+    small.scale = 2e-3 * args.scale
+    lengths = rank_corpus(small, rank, world, host_shard_cuts)
     offsets = np.concatenate([[0], np.cumsum(lengths)[:-1]]).astype(np.uint64)
     base = np.random.default_rng(rank).integers(0, 256, size=int(lengths.sum()) + 1, dtype=np.uint8)
     if world > 1:
@@ -439,7 +477,8 @@ def dry_run(args, rank, world):
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         job_bytes = float(tot.item())
     if rank == 0:
-        print(json.dumps({"dry_run": True, "n_gpus": world, "steps": args.steps, "scaling": "weak",
+        print(json.dumps({"dry_run": True, "n_gpus": world, "steps": args.steps,
+                          "scaling": "strong" if args.strong and world > 1 else "weak",
                           "value": job_bytes * args.steps / elapsed / GB, "unit": "GB/s",
                           "job_bytes": job_bytes, "files_rank0": int(len(lengths)),
                           "digest0": digests[0].tobytes().hex()}), flush=True)
@@ -482,6 +521,9 @@ def main():
     ap.add_argument("--archives", type=int, default=8, help="mcdf workload: archives per GPU")
     ap.add_argument("--archive-mib", type=float, default=128.0, help="mcdf workload: decoded MiB per archive")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink or grow the corpus")
+    ap.add_argument("--strong", action="store_true",
+                    help="one corpus for the whole job, sharded by file over the ranks (default: every "
+                         "rank has a corpus of its own, weak scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-dry-run", action="store_true",
                     help="no GPU: exercise the multi-rank plumbing with the CPU oracle standing in for the "
@@ -540,8 +582,7 @@ def main():
             dist.destroy_process_group()
         return
 
-    rng = np.random.default_rng(0x534E4150 + rank)
-    lengths = make_sizes(args.workload, rng, args.scale)
+    lengths = rank_corpus(args, rank, world, lambda L, k: shard_cuts(native.lib(), L, k))
     offsets = np.concatenate([[0], np.cumsum(lengths)[:-1]]).astype(np.uint64)
     total_bytes = int(lengths.sum())
     algo_bytes = int(padded_blocks(lengths).sum()) * 64
@@ -618,7 +659,7 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if args.strong and world > 1 else "weak",
         "vs_baseline": None,
         "dtype": "u32",
         "data": "synthetic",
@@ -627,7 +668,8 @@ def main():
                          "small": "10^6 files of 4-32 KB per GPU, SHA-1, data + (offset,len) table + digests resident in HBM",
                          "folder": "one snapshot folder (160 files, ~200 MB), SHA-1, inputs resident in HBM",
                          "corpus": "mixed asset corpus (70 pct .tex-like 256 KB-22 MB, 30 pct .mdl-like 64 KB-6 MB), "
-                                   + f"{100 * args.scale:.1f} GB per GPU, SHA-1, inputs resident in HBM"}[args.workload],
+                                   + f"{100 * args.scale:.1f} GB per {'job' if args.strong and world > 1 else 'GPU'}, "
+                                   + "SHA-1, inputs resident in HBM"}[args.workload],
             "files_per_gpu": n,
             "bytes_per_gpu": total_bytes,
             "largest_file_bytes": int(lengths.max()),

@@ -33,6 +33,26 @@ def test_bench_two_ranks_gloo(tmp_path):
     assert one["digest0"] == d["digest0"]         # rank 0 hashes the same corpus either way
 
 
+def test_bench_two_ranks_strong_scaling(tmp_path):
+    """--strong: one corpus for the job, sharded by file; the ranks' bytes add up to it."""
+    def run(n):
+        cmd = [sys.executable, os.path.join(H.ROOT, "bench.py")]
+        if n > 1:
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+                   "--master-addr", "127.0.0.1", "--master-port", "29751", os.path.join(H.ROOT, "bench.py")]
+        cmd += ["--gpus", str(n), "--steps", "1", "--warmup", "0", "--cpu-dry-run", "--strong",
+                "--workload", "corpus", "--scale", "0.2"]
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=240, cwd=H.ROOT)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+
+    one, two = run(1), run(2)
+    assert two["scaling"] == "strong" and one["scaling"] == "weak"
+    assert two["job_bytes"] == one["job_bytes"]
+    assert two["digest0"] == one["digest0"]           # rank 0's shard starts with the corpus' first file
+    assert 0 < two["files_rank0"] < one["files_rank0"]
+
+
 def _worker(rank, world, port, lengths, seed, ret):
     import torch.distributed as dist
 
@@ -90,6 +110,10 @@ def test_plan_shards_properties(snappy):
         ln = rng.integers(0, 1 << 20, size=n).astype(np.uint64)
         cuts = plan_shards(ln, k)
         assert cuts[0] == 0 and cuts[-1] == n and np.all(np.diff(cuts.astype(np.int64)) >= 0)
+        sys.path.insert(0, H.ROOT)
+        import bench
+
+        assert np.array_equal(bench.host_shard_cuts(ln, k), cuts)   # bench's dry-run restatement
         if n >= 100:
             per = np.array([ln[int(cuts[i]): int(cuts[i + 1])].sum() for i in range(k)], dtype=np.float64)
             assert per.max() <= ln.sum() / k + ln.max()
