@@ -34,6 +34,7 @@ int create_slot(Slot &s)
         for (int j = 0; j < 2; ++j)
             SNAPPY_HIP_TRY(hipEventCreate(&s.ev_prof[k][j]));
     s.h_stage.pinned_host = true;
+    s.h_ring.pinned_host = true;
     return SNAPPY_OK;
 }
 
@@ -45,6 +46,7 @@ void destroy_slot(Slot &s)
     s.d_out.release();
     s.d_misc.release();
     s.h_stage.release();
+    s.h_ring.release();
     for (int k = 0; k < kProfileKernels; ++k)
         for (int j = 0; j < 2; ++j)
             if (s.ev_prof[k][j])

@@ -56,6 +56,7 @@ struct Slot {
     Buffer d_out;      // digests / statuses
     Buffer d_misc;     // queue counters, error words
     Buffer h_stage;    // pinned host staging (tasks up, digests down)
+    Buffer h_ring;     // pinned ring through which pageable sources travel to the device
     bool busy = false;
 };
 

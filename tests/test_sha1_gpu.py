@@ -251,3 +251,28 @@ def test_hash_while_copying(snappy, oracle, slice_bytes):
         base = rng.integers(0, 256, size=int(sizes.sum()) + 1, dtype=np.uint8)
         assert np.array_equal(snappy.sha1_batch(base, offsets, sizes),
                               oracle.sha1_batch_np(base, offsets, sizes)), path
+
+
+def test_page_locked_sources(snappy, oracle):
+    """Files read into memory from snappy_host_alloc travel by direct DMA (no staging ring)."""
+    import ctypes
+
+    os.environ["SNAPPY_OVERLAP_MIN_BYTES"] = "0"
+    os.environ["SNAPPY_OVERLAP_SLICE_BYTES"] = "262144"
+    L = snappy.native.lib()
+    rng = np.random.default_rng(71)
+    sizes = rng.integers(0, 600_000, size=50).astype(np.uint64)
+    total = int(sizes.sum())
+    ptr = ctypes.c_void_p()
+    assert L.snappy_host_alloc(total + 1, ctypes.byref(ptr)) == 0
+    try:
+        pinned = np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(ctypes.c_uint8)), shape=(total + 1,))
+        pinned[:] = rng.integers(0, 256, size=total + 1, dtype=np.uint8)
+        offsets = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.uint64)
+        want = oracle.sha1_batch_np(pinned, offsets, sizes)
+        assert np.array_equal(snappy.sha1_batch(pinned, offsets, sizes), want)
+        del pinned
+    finally:
+        assert L.snappy_host_free(ptr) == 0
+    assert L.snappy_host_alloc(0, ctypes.byref(ptr)) == 0 and not ptr.value
+    assert L.snappy_host_free(None) == 0
