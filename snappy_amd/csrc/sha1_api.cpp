@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <cstddef>
+#include <cstdio>
 #include <cstdlib>
 #include <condition_variable>
 #include <cstring>
@@ -23,11 +24,17 @@ namespace {
 // of 64 / 16 / 4 / 1 lanes per message).  chain: nanoseconds a message spends
 // per 64-byte block when its wavefront has a SIMD to itself (one instruction
 // issues per ~4.2 cycles; 412 instructions per block on the chain plus the
-// schedule expansion shared by the group; the clock falls from ~2.4 GHz to
-// ~1.7 GHz as more lanes do real work).  simd: SIMD time a block costs.
-constexpr double kChainNs[kSha1Paths] = {723.0, 799.0, 985.0, 1667.0};
+// schedule expansion shared by the group).  simd: SIMD time a block costs.
+// The one-lane chain runs at 1300-1670 ns per block when the whole chip does
+// one-lane work, but next to wide-group waves on a mixed corpus files of 6-10 MB
+// were seen at up to ~2800 ns per block, and their waves then decided the
+// finishing time (270-440 ms per step instead of a steady 262 ms): the planner
+// is told the pessimistic figure, which sends such files to the 4-lane path.
+constexpr double kChainNs[kSha1Paths] = {723.0, 799.0, 985.0, 3000.0};
 constexpr double kSimdNs[kSha1Paths] = {723.0, 199.7, 61.6, 26.0};
-constexpr double kSlowPathMargin = 0.6;
+
+// How much slower chains run when all SIMDs are busy (the clock drops under load).
+constexpr double kLoadSlowdown = 0.45;
 
 long env_long(const char *name, long fallback)
 {
@@ -59,8 +66,13 @@ int enqueue_sha1_resident(SlotLease &lease, const uint8_t *d_base, const uint64_
         model.chain_ns[k] = kChainNs[k];
         model.simd_ns[k] = kSimdNs[k];
     }
+    if (const char *v = std::getenv("SNAPPY_SHA1_CHAIN_NS"))  // tuning: "c0,c1,c2,c3"
+        std::sscanf(v, "%lf,%lf,%lf,%lf", &model.chain_ns[0], &model.chain_ns[1], &model.chain_ns[2],
+                    &model.chain_ns[3]);
     model.n_simd = n_simd;
-    model.slow_path_margin = kSlowPathMargin;
+    model.load_slowdown = kLoadSlowdown;
+    if (const char *v = std::getenv("SNAPPY_SHA1_LOAD_SLOWDOWN"))  // tuning
+        model.load_slowdown = std::atof(v);
     // SNAPPY_SHA1_FORCE_PATH = 0..3 sends every message down one path (tests, tuning).
     model.forced_path = static_cast<int>(env_long("SNAPPY_SHA1_FORCE_PATH", -1));
     if (model.forced_path >= kSha1Paths)
@@ -77,8 +89,13 @@ int enqueue_sha1_resident(SlotLease &lease, const uint8_t *d_base, const uint64_
         SNAPPY_HIP_TRY(hipEventRecord(s.ev_prof[0][0], stream));
     SNAPPY_HIP_TRY(
         launch_sha1_plan(d_offsets, d_lengths, d_epochs, n32, d_state, d_tasks, model, stream));
-    SNAPPY_HIP_TRY(
-        launch_sha1_hop(d_base, d_tasks, d_state, d_digests, d_arrival, n32, n_simd, stream));
+    // Only a batch with at least two full waves of one-lane work per SIMD can be
+    // given a second wave per SIMD by the planner: do not launch what must leave.
+    const int launch_rounds =
+        (d_arrival == nullptr && n >= 128ull * n_simd) ? kMaxWavesPerSimd : 1;
+    SNAPPY_HIP_TRY(launch_sha1_hop(d_base, d_tasks, d_state, d_digests, d_arrival, n32, n_simd,
+                                   static_cast<int>(env_long("SNAPPY_HOP_GRID_ROUNDS", launch_rounds)),
+                                   stream));
     if (prof)
         SNAPPY_HIP_TRY(hipEventRecord(s.ev_prof[0][1], stream));
     return SNAPPY_OK;

@@ -222,11 +222,10 @@ __device__ __forceinline__ HopResult hop_once(const uint8_t *__restrict__ base,
 __global__ void __launch_bounds__(kWave)
 sha1_hop_kernel(const uint8_t *__restrict__ base, const Sha1Task *__restrict__ tasks,
                 Sha1PlanState *__restrict__ state, uint8_t *__restrict__ digests,
-                Sha1Arrival *arrival)
+                Sha1Arrival *arrival, uint32_t per_simd_round)
 {
     const uint32_t lane = lane_id();
-    if (blockIdx.x >= gridDim.x / kMaxWavesPerSimd *
-                          __builtin_amdgcn_readfirstlane(state->waves_per_simd))
+    if (blockIdx.x >= per_simd_round * __builtin_amdgcn_readfirstlane(state->waves_per_simd))
         return;
     uint32_t lo[kSha1Paths], hi[kSha1Paths];
     float chain[kSha1Paths];
@@ -277,14 +276,15 @@ sha1_hop_kernel(const uint8_t *__restrict__ base, const Sha1Task *__restrict__ t
 
 hipError_t launch_sha1_hop(const uint8_t *d_base, const Sha1Task *d_tasks, Sha1PlanState *d_state,
                            uint8_t *d_digests, Sha1Arrival *d_arrival, uint32_t n, uint32_t n_simd,
-                           hipStream_t stream)
+                           int waves_per_simd, hipStream_t stream)
 {
     if (n == 0)
         return hipSuccess;
-    // A multiple of kMaxWavesPerSimd, so that the kernel's cut-off is exact.
+    // `per` workgroups make one wave per SIMD; the planner's waves_per_simd decides
+    // how many of the launched rounds stay.
     const uint32_t per = n < n_simd ? n : n_simd;
-    hipLaunchKernelGGL(sha1_hop_kernel, dim3(per * kMaxWavesPerSimd), dim3(kWave), 0, stream,
-                       d_base, d_tasks, d_state, d_digests, d_arrival);
+    hipLaunchKernelGGL(sha1_hop_kernel, dim3(per * static_cast<uint32_t>(waves_per_simd)),
+                       dim3(kWave), 0, stream, d_base, d_tasks, d_state, d_digests, d_arrival, per);
     return hipGetLastError();
 }
 

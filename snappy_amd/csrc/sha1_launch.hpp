@@ -25,7 +25,7 @@ constexpr int kHopGroupLanes[kSha1Paths] = {64, 16, 4, 1};
 struct Sha1CostModel {
     double chain_ns[kSha1Paths];
     double simd_ns[kSha1Paths];
-    double slow_path_margin;  // paths 1..3 only take messages whose chain fits in this share of T
+    double load_slowdown;     // chains run up to (1 + this) times slower when every SIMD is busy
     uint32_t n_simd;
     int forced_path;          // >= 0: everything takes this path (testing / tuning)
     int forced_waves;         // > 0: waves per SIMD (testing / tuning)
@@ -74,6 +74,6 @@ constexpr int kMaxWavesPerSimd = 2;
 // d_arrival (may be null): see Sha1Arrival.
 hipError_t launch_sha1_hop(const uint8_t *d_base, const Sha1Task *d_tasks,
                            Sha1PlanState *d_state, uint8_t *d_digests, Sha1Arrival *d_arrival,
-                           uint32_t n, uint32_t n_simd, hipStream_t stream);
+                           uint32_t n, uint32_t n_simd, int waves_per_simd, hipStream_t stream);
 
 }  // namespace snappy

@@ -83,20 +83,24 @@ plan_histogram(const uint64_t *__restrict__ lengths, uint32_t n, Sha1PlanState *
 
 // Pass 2 (one workgroup): bucket start positions and the cuts between paths.
 //
-// The batch cannot finish before its largest message's chain on the fastest
-// path, nor before its total SIMD time has been spent on the n_simd SIMDs.  For a
-// finishing time T a bucket may take path k when its largest possible message
-// would finish well in time on that path (edge * chain_ns[k] <= margin * T, so
-// that work on the slower paths comes in pieces that still pack into T), and
-// the cheapest such path is the best one for it.  T is feasible when the SIMD time of that
-// assignment fits into T * n_simd; the smallest feasible T is found by
-// bisection and its assignment becomes the plan.  Sizes fall along the sorted
-// list, so every path's buckets are consecutive.
-__device__ __forceinline__ int cheapest_path(double edge_blocks, double t, const Sha1CostModel &m,
-                                             int last_path)
+// The kernel hands out wave-sized pieces of work longest first (a piece = the
+// 64 / G files one wave takes together; its duration = its largest file's
+// blocks x chain_ns of the path).  For m SIMDs such a schedule finishes no later
+// than max(d_1, W + d_(m+1)): the longest piece, or the average load W (total
+// SIMD time / m) plus the longest piece that does not start at once.  The cut is
+// a one-parameter family: with D the longest duration allowed on paths 1..3, a
+// size bucket takes the cheapest of those paths on which it stays within D, and
+// path 0 (the fastest chain, the most SIMD time) otherwise.  A large D means
+// little work but long late pieces, a small D the opposite; the D with the
+// smallest bound is searched on a geometric grid.
+constexpr int kCoarseCandidates = 22;  // 11 octaves
+constexpr int kFineCandidates = 14;    // one octave around the coarse optimum
+constexpr int kPlanCandidates = kCoarseCandidates + (kSha1Paths - 1) + kFineCandidates;
+
+__device__ __forceinline__ int path_for(double edge_blocks, double d_max, const Sha1CostModel &m)
 {
-    for (int k = last_path; k > 0; --k)
-        if (edge_blocks * m.chain_ns[k] <= m.slow_path_margin * t)
+    for (int k = kSha1Paths - 1; k > 0; --k)
+        if (edge_blocks * m.chain_ns[k] <= d_max)
             return k;
     return 0;
 }
@@ -106,7 +110,12 @@ plan_scan(Sha1PlanState *__restrict__ st, uint32_t n, Sha1CostModel m)
 {
     __shared__ uint32_t scan[kPlanBuckets];
     __shared__ uint32_t used[kPlanBuckets];  // positions of the non-empty buckets
+    __shared__ float dur[kPlanBuckets];      // per used bucket, for the candidate at hand:
+    __shared__ uint32_t pieces[kPlanBuckets];  //   duration of a piece, number of pieces,
+    __shared__ double work[kPlanBuckets];      //   SIMD time
     __shared__ uint32_t n_used;
+    __shared__ float d_late;   // duration of the first piece that has to wait for a SIMD
+    __shared__ double best_bound, best_d;
     const uint32_t k = threadIdx.x;
     const uint32_t count = st->hist[k];
     scan[k] = count;
@@ -123,64 +132,107 @@ plan_scan(Sha1PlanState *__restrict__ st, uint32_t n, Sha1CostModel m)
     if (count)
         used[atomicAdd(&n_used, 1u)] = k;
     __syncthreads();
+
+    const double max_blocks = static_cast<double>(st->max_blocks);
+    const double simds = static_cast<double>(m.n_simd);
+    const uint32_t u_count = n_used;
+    const uint32_t pos = k < u_count ? used[k] : 0u;
+    const double edge = fmin(bucket_floor(kPlanBuckets - pos), max_blocks);  // largest file possible
+    const double blocks = k < u_count ? static_cast<double>(st->blocks[pos]) : 0.0;
+    const uint32_t files = k < u_count ? st->hist[pos] : 0u;
+
+    if (m.forced_path < 0) {
+        if (k == 0) {
+            best_bound = -1.0;
+            best_d = 0.0;
+        }
+        // Coarse pass: from "everything may take the slowest path" down by sqrt(2)
+        // per step; then the largest file's own thresholds (just below them it moves
+        // to the next faster path while everything else keeps the most room); then a
+        // fine pass around the best so far.
+        const double d_top = max_blocks * m.chain_ns[kSha1Paths - 1] * 1.0001;
+        for (int c = 0; c < kPlanCandidates; ++c) {
+            double d_max;
+            if (c < kCoarseCandidates)
+                d_max = d_top * exp2(-0.5 * static_cast<double>(c));
+            else if (c < kCoarseCandidates + kSha1Paths - 1)
+                d_max = max_blocks * m.chain_ns[c - kCoarseCandidates + 1] * 0.9999;
+            else
+                d_max = best_d * exp2((static_cast<double>(c - kCoarseCandidates - kSha1Paths + 1) -
+                                       0.5 * (kFineCandidates - 1)) / kFineCandidates);
+            if (k < u_count) {
+                const int path = path_for(edge, d_max, m);
+                const uint32_t per_wave = 64u / static_cast<uint32_t>(kHopGroupLanes[path]);
+                dur[k] = static_cast<float>(edge * m.chain_ns[path]);
+                pieces[k] = (files + per_wave - 1) / per_wave;
+                work[k] = blocks * m.simd_ns[path];
+            }
+            if (k == 0)
+                d_late = 0.f;
+            __syncthreads();
+            if (k < u_count) {
+                // Pieces that are handed out before this bucket's.
+                uint32_t before = 0;
+                const float mine = dur[k];
+                for (uint32_t v = 0; v < u_count; ++v)
+                    if (dur[v] > mine || (dur[v] == mine && v < k))
+                        before += pieces[v];
+                if (before <= m.n_simd && m.n_simd < before + pieces[k])
+                    d_late = mine;
+            }
+            __syncthreads();
+            if (k == 0) {
+                double total = 0.0, longest = 0.0;
+                for (uint32_t v = 0; v < u_count; ++v) {
+                    total += work[v];
+                    longest = fmax(longest, static_cast<double>(dur[v]));
+                }
+                // The busier the chip, the lower its clock: scale the chains by the
+                // share of SIMD time in use.
+                const double load = total / simds;
+                const double first = fmax(longest, load + static_cast<double>(d_late));
+                const double slow = 1.0 + m.load_slowdown * fmin(1.0, load / first);
+                const double bound = fmax(longest * slow, load + static_cast<double>(d_late) * slow);
+                // Move on only for a clear gain.
+                if (best_bound < 0.0 || bound < 0.98 * best_bound) {
+                    best_bound = bound;
+                    best_d = d_max;
+                }
+            }
+            __syncthreads();
+        }
+    }
     if (k != 0)
         return;
 
     uint32_t cut[kSha1Paths];
     for (int q = 0; q < kSha1Paths; ++q)
         cut[q] = 0;
-    double planned = 0.0;
     uint32_t waves = 1;
     if (m.forced_path >= 0) {
         for (int q = m.forced_path; q < kSha1Paths; ++q)
             cut[q] = n;
     } else {
-        const double max_blocks = static_cast<double>(st->max_blocks);
-        const double total = static_cast<double>(st->total_blocks);
-        const double simds = static_cast<double>(m.n_simd);
-        const int last_path = kSha1Paths - 1;
-        double lo = max_blocks * m.chain_ns[0];
-        double hi = lo + total * m.simd_ns[0] / simds;  // everything on path 0 fits into this
-        for (int it = 0; it < 24 && hi > 1.002 * lo; ++it) {
-            const double t = sqrt(lo * hi);
-            double work = 0.0;
-            for (uint32_t u = 0; u < n_used; ++u) {
-                const uint32_t pos = used[u];
-                const double edge = fmin(bucket_floor(kPlanBuckets - pos), max_blocks);
-                work += static_cast<double>(st->blocks[pos]) *
-                        m.simd_ns[cheapest_path(edge, t, m, last_path)];
-            }
-            if (work <= t * simds)
-                hi = t;
-            else
-                lo = t;
-        }
-        planned = hi;
-        for (uint32_t u = 0; u < n_used; ++u) {
-            const uint32_t pos = used[u];
-            const double edge = fmin(bucket_floor(kPlanBuckets - pos), max_blocks);
-            const int path = cheapest_path(edge, hi, m, last_path);
-            if (scan[pos] > cut[path])
-                cut[path] = scan[pos];
+        // When nearly all the SIMD time goes into one-lane groups the batch is a
+        // throughput job: a second wave per SIMD then hides what the first one
+        // waits for.  Otherwise chains matter and a shared SIMD would halve their speed.
+        double bulk = 0.0, all = 0.0;
+        for (uint32_t u = 0; u < u_count; ++u) {
+            const uint32_t p = used[u];
+            const double e = fmin(bucket_floor(kPlanBuckets - p), max_blocks);
+            const int path = path_for(e, best_d, m);
+            if (scan[p] > cut[path])
+                cut[path] = scan[p];
+            const double w = static_cast<double>(st->blocks[p]) * m.simd_ns[path];
+            all += w;
+            if (path == kSha1Paths - 1)
+                bulk += w;
         }
         // Ends of empty paths follow their predecessor; the last path ends the list.
         for (int q = 1; q < kSha1Paths; ++q)
             if (cut[q] < cut[q - 1])
                 cut[q] = cut[q - 1];
         cut[kSha1Paths - 1] = n;
-        // When nearly all the SIMD time goes into one-lane groups the batch is a
-        // throughput job: a second wave per SIMD then hides what the first one
-        // waits for.  Otherwise chains matter and a shared SIMD would halve their speed.
-        double bulk = 0.0, all = 0.0;
-        for (uint32_t u = 0; u < n_used; ++u) {
-            const uint32_t pos = used[u];
-            const double edge = fmin(bucket_floor(kPlanBuckets - pos), max_blocks);
-            const int path = cheapest_path(edge, hi, m, last_path);
-            const double w = static_cast<double>(st->blocks[pos]) * m.simd_ns[path];
-            all += w;
-            if (path == kSha1Paths - 1)
-                bulk += w;
-        }
         waves = (bulk >= 0.9 * all && n >= 128u * m.n_simd) ? 2u : 1u;
     }
     for (int q = 0; q < kSha1Paths; ++q)
@@ -190,7 +242,7 @@ plan_scan(Sha1PlanState *__restrict__ st, uint32_t n, Sha1CostModel m)
     if (m.forced_waves > 0)
         waves = m.forced_waves < kMaxWavesPerSimd ? m.forced_waves : kMaxWavesPerSimd;
     st->waves_per_simd = waves;
-    st->planned_ns = planned;
+    st->planned_ns = m.forced_path >= 0 ? 0.0 : best_bound;
 }
 
 // Pass 3: scatter the tasks to their bucket ranges.  A workgroup counts its files
