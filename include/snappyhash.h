@@ -206,11 +206,39 @@ int snappy_store_files(const char *const *paths, uint64_t n, const char *files_d
 int snappy_mcdf_import_to_dir(const char *mcdf_path, const char *working_dir,
                               char *snapshot_dir_out, uint64_t out_cap);
 
+/* ------------------------------------------------- the write side (archives) */
+
+/* McdfHeader.WriteToStream (Snappy/Features/Mcdf/McdfHeader.cs:14-24) with
+ * McdfData.ToByteArray (McdfData.cs:15-18): "MCDF", version 1, int32 length,
+ * compact JSON {Description, GlamourerData, CustomizePlusData, ManipulationData,
+ * Files:[{GamePaths:[...], Length}]}.  Strings are UTF-8 (NULL = empty).
+ * game_paths holds all files' paths one file after the other, paths_per_file[i]
+ * of them for file i.  *out_len receives the size; SNAPPY_E_CAPACITY when
+ * out_cap is smaller (nothing written).  Host only. */
+int snappy_mcdf_write_header(const char *description, const char *glamourer_data,
+                             const char *customize_plus_data, const char *manipulation_data,
+                             const char *const *game_paths, const uint32_t *paths_per_file,
+                             const int64_t *lengths, uint64_t n_files, uint8_t *out,
+                             uint64_t out_cap, uint64_t *out_len);
+
+/* The inverse of snappy_lz4net_decode: what writing `in` through
+ * `new LZ4Stream(fs, LZ4StreamMode.Compress, ...)` produces in framing (the
+ * stream McdfManager.cs:72-80 reads back): one chunk per block_size input bytes
+ * (0 = lz4net's default, 1 MiB), each compressed as one LZ4 block on the GPU and
+ * stored uncompressed when it does not shrink.  The blocks are valid LZ4 and
+ * decode to `in`; they are not byte-identical with lz4net's own compressor.
+ * The reference itself never writes an archive (WriteToStream has no caller).
+ * snappy_lz4net_encode_bound gives a sufficient out_cap; with a smaller one the
+ * call returns SNAPPY_E_CAPACITY and *out_len = the size needed. */
+int snappy_lz4net_encode_bound(uint64_t in_len, uint32_t block_size, uint64_t *bound);
+int snappy_lz4net_encode(const uint8_t *in, uint64_t in_len, uint32_t block_size,
+                         uint8_t *out, uint64_t out_cap, uint64_t *out_len);
+
 /* --------------------------------------------------------------- profiling */
 
 /* Kernel timing of the most recent compute call made by this thread, measured
  * with HIP events recorded on the stream the kernels ran on.  kernel: 0 = SHA-1
- * kernels, 1 = LZ4 decode kernel.  Returns milliseconds, or a negative value
+ * kernels, 1 = LZ4 decode (or encode) kernel.  Returns milliseconds, or a negative value
  * when that kernel did not run.  snappy_profile_enable(1) turns recording on
  * (off by default).  No counterpart in the reference. */
 void snappy_profile_enable(int on);

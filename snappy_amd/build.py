@@ -18,7 +18,7 @@ LIB = os.path.join(HERE, "libsnappyhash.so")
 SOURCES = [
     "sha1_kernels.hip",
     "sha1_plan.hip",
-    "lz4_kernels.hip",
+    "lz4_kernels.hip", "lz4_encode.hip",
     "runtime.cpp",
     "sha1_api.cpp",
     "lz4net_host.cpp",

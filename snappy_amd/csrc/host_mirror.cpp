@@ -394,6 +394,50 @@ extern "C" int snappy_store_files(const char *const *paths, uint64_t n, const ch
     return SNAPPY_OK;
 }
 
+// McdfHeader.WriteToStream (McdfHeader.cs:14-24) over McdfData.ToByteArray
+// (McdfData.cs:15-18, JsonConvert.SerializeObject without formatting: properties
+// in declaration order, no spaces).
+extern "C" int snappy_mcdf_write_header(const char *description, const char *glamourer_data,
+                                        const char *customize_plus_data,
+                                        const char *manipulation_data,
+                                        const char *const *game_paths,
+                                        const uint32_t *paths_per_file, const int64_t *lengths,
+                                        uint64_t n_files, uint8_t *out, uint64_t out_cap,
+                                        uint64_t *out_len)
+{
+    if (!out_len || (!out && out_cap) || (n_files && (!paths_per_file || !lengths)))
+        return SNAPPY_E_INVALID_ARG;
+    auto text = [](const char *s) { return json_string(s ? s : ""); };
+    std::string js = "{\"Description\":" + text(description) + ",\"GlamourerData\":" +
+                     text(glamourer_data) + ",\"CustomizePlusData\":" + text(customize_plus_data) +
+                     ",\"ManipulationData\":" + text(manipulation_data) + ",\"Files\":[";
+    uint64_t next_path = 0;
+    for (uint64_t i = 0; i < n_files; ++i) {
+        js += i ? ",{\"GamePaths\":[" : "{\"GamePaths\":[";
+        for (uint32_t k = 0; k < paths_per_file[i]; ++k) {
+            if (!game_paths || !game_paths[next_path])
+                return SNAPPY_E_INVALID_ARG;
+            js += (k ? "," : "") + json_string(game_paths[next_path++]);
+        }
+        js += "],\"Length\":" + std::to_string(static_cast<long long>(lengths[i])) + "}";
+    }
+    js += "]}";
+    if (js.size() > 0x7FFFFFFFull)
+        return SNAPPY_E_INVALID_ARG;  // BinaryWriter.Write(int)
+    *out_len = 9 + js.size();
+    if (*out_len > out_cap)
+        return SNAPPY_E_CAPACITY;
+    std::memcpy(out, "MCDF", 4);
+    out[4] = 1;  // McdfHeader.CurrentVersion
+    const uint32_t n = static_cast<uint32_t>(js.size());
+    out[5] = static_cast<uint8_t>(n);
+    out[6] = static_cast<uint8_t>(n >> 8);
+    out[7] = static_cast<uint8_t>(n >> 16);
+    out[8] = static_cast<uint8_t>(n >> 24);
+    std::memcpy(out + 9, js.data(), js.size());
+    return SNAPPY_OK;
+}
+
 extern "C" int snappy_mcdf_import_to_dir(const char *mcdf_path, const char *working_dir,
                                          char *snapshot_dir_out, uint64_t out_cap)
 {

@@ -1,4 +1,5 @@
-// Host-side launch interface of the LZ4 decode kernel (lz4_kernels.hip).
+// Host-side launch interface of the LZ4 decode kernel (lz4_kernels.hip) and of
+// the LZ4 compressor (lz4_encode.hip).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -23,5 +24,19 @@ struct Lz4Chunk {
 hipError_t launch_lz4_decode(const uint8_t *d_in, uint64_t in_alloc, uint8_t *d_out,
                              const Lz4Chunk *d_chunks, uint32_t n_chunks, uint32_t *d_queue,
                              uint32_t *d_status, int blocks, hipStream_t stream);
+
+// One chunk to compress: in_len bytes at d_in + in_off; the block is written at
+// d_out + out_off, where in_len + in_len / 255 + 16 bytes must be available.
+struct Lz4EncChunk {
+    uint64_t in_off;
+    uint64_t out_off;
+    uint32_t in_len;
+    uint32_t reserved;
+};
+
+// Compresses n_chunks chunks, one per wavefront; d_out_sizes[i] receives the
+// size of block i.
+hipError_t launch_lz4_encode(const uint8_t *d_in, uint8_t *d_out, const Lz4EncChunk *d_chunks,
+                             uint32_t n_chunks, uint32_t *d_out_sizes, hipStream_t stream);
 
 }  // namespace snappy

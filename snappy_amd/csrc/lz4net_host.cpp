@@ -251,3 +251,131 @@ extern "C" int snappy_lz4net_decode(const uint8_t *in, uint64_t in_len, uint8_t 
     *out_len = dec.size;
     return SNAPPY_OK;
 }
+
+// ---------------------------------------------------------------------------
+// The write side: lz4net LZ4Stream framing around blocks compressed on the GPU.
+// ---------------------------------------------------------------------------
+namespace {
+
+uint64_t put_varint(uint8_t *out, uint64_t o, uint64_t v)
+{
+    while (v >= 0x80) {
+        out[o++] = static_cast<uint8_t>(v | 0x80);
+        v >>= 7;
+    }
+    out[o++] = static_cast<uint8_t>(v);
+    return o;
+}
+
+uint64_t varint_size(uint64_t v)
+{
+    uint64_t n = 1;
+    while (v >= 0x80) {
+        ++n;
+        v >>= 7;
+    }
+    return n;
+}
+
+constexpr uint32_t kDefaultBlockSize = 1u << 20;  // LZ4Stream's default
+constexpr uint32_t kMaxBlockSize = 1u << 30;
+
+}  // namespace
+
+extern "C" int snappy_lz4net_encode_bound(uint64_t in_len, uint32_t block_size, uint64_t *bound)
+{
+    if (!bound || block_size > kMaxBlockSize)
+        return SNAPPY_E_INVALID_ARG;
+    const uint64_t bs = block_size ? block_size : kDefaultBlockSize;
+    const uint64_t chunks = (in_len + bs - 1) / bs;
+    *bound = in_len + chunks * 16 + 16;
+    return SNAPPY_OK;
+}
+
+extern "C" int snappy_lz4net_encode(const uint8_t *in, uint64_t in_len, uint32_t block_size,
+                                    uint8_t *out, uint64_t out_cap, uint64_t *out_len)
+{
+    if ((!in && in_len) || !out_len || (!out && out_cap) || block_size > kMaxBlockSize)
+        return SNAPPY_E_INVALID_ARG;
+    *out_len = 0;
+    if (in_len == 0)
+        return SNAPPY_OK;  // LZ4Stream writes nothing for an empty input
+    const uint64_t bs = block_size ? block_size : kDefaultBlockSize;
+    const uint64_t n_chunks = (in_len + bs - 1) / bs;
+    if (n_chunks >= 0x7FFFFFFFull)
+        return SNAPPY_E_INVALID_ARG;
+
+    SlotLease lease;
+    int st = lease.acquire(pick_device());
+    if (st != SNAPPY_OK)
+        return st;
+    Slot &s = *lease.slot;
+    profile_reset();
+
+    // Arena: [input][one worst-case output area per chunk].
+    const uint64_t area = (bs + bs / 255 + 16 + 15) & ~uint64_t(15);
+    const uint64_t in_area = (in_len + 15) & ~uint64_t(15);
+    std::vector<Lz4EncChunk> chunks(n_chunks);
+    for (uint64_t k = 0; k < n_chunks; ++k) {
+        chunks[k].in_off = k * bs;
+        chunks[k].out_off = in_area + k * area;
+        chunks[k].in_len = static_cast<uint32_t>(std::min<uint64_t>(bs, in_len - k * bs));
+        chunks[k].reserved = 0;
+    }
+    if ((st = s.d_data.ensure(in_area + n_chunks * area)) != SNAPPY_OK) return st;
+    if ((st = s.d_tasks.ensure(n_chunks * sizeof(Lz4EncChunk))) != SNAPPY_OK) return st;
+    if ((st = s.d_out.ensure(n_chunks * sizeof(uint32_t))) != SNAPPY_OK) return st;
+    uint8_t *d_base = static_cast<uint8_t *>(s.d_data.ptr);
+    Lz4EncChunk *d_chunks = static_cast<Lz4EncChunk *>(s.d_tasks.ptr);
+    uint32_t *d_sizes = static_cast<uint32_t *>(s.d_out.ptr);
+    SNAPPY_HIP_TRY(hipMemcpyAsync(d_base, in, in_len, hipMemcpyHostToDevice, s.stream));
+    SNAPPY_HIP_TRY(hipMemcpyAsync(d_chunks, chunks.data(), n_chunks * sizeof(Lz4EncChunk),
+                                  hipMemcpyHostToDevice, s.stream));
+    const bool prof = profiling_enabled();
+    if (prof)
+        SNAPPY_HIP_TRY(hipEventRecord(s.ev_prof[1][0], s.stream));
+    SNAPPY_HIP_TRY(launch_lz4_encode(d_base, d_base, d_chunks, static_cast<uint32_t>(n_chunks),
+                                     d_sizes, s.stream));
+    if (prof)
+        SNAPPY_HIP_TRY(hipEventRecord(s.ev_prof[1][1], s.stream));
+    std::vector<uint32_t> sizes(n_chunks);
+    SNAPPY_HIP_TRY(hipMemcpyAsync(sizes.data(), d_sizes, n_chunks * sizeof(uint32_t),
+                                  hipMemcpyDeviceToHost, s.stream));
+    SNAPPY_HIP_TRY(hipStreamSynchronize(s.stream));
+    if (prof) {
+        float ms = -1.f;
+        if (hipEventElapsedTime(&ms, s.ev_prof[1][0], s.ev_prof[1][1]) == hipSuccess)
+            profile_store(1, ms);
+        else
+            (void)hipGetLastError();
+    }
+
+    // FlushCurrentChunk: flags (bit 0 = compressed), original length, compressed
+    // length when compressed, payload; a block that does not shrink is stored.
+    uint64_t need = 0;
+    for (uint64_t k = 0; k < n_chunks; ++k) {
+        const uint64_t n = chunks[k].in_len, c = sizes[k];
+        need += 1 + varint_size(n) + (c < n ? varint_size(c) + c : n);
+    }
+    *out_len = need;
+    if (need > out_cap)
+        return SNAPPY_E_CAPACITY;
+    uint64_t o = 0;
+    for (uint64_t k = 0; k < n_chunks; ++k) {
+        const uint64_t n = chunks[k].in_len, c = sizes[k];
+        const bool compressed = c < n;
+        o = put_varint(out, o, compressed ? 1u : 0u);
+        o = put_varint(out, o, n);
+        if (compressed) {
+            o = put_varint(out, o, c);
+            SNAPPY_HIP_TRY(hipMemcpyAsync(out + o, d_base + chunks[k].out_off, c,
+                                          hipMemcpyDeviceToHost, s.stream));
+            o += c;
+        } else {
+            std::memcpy(out + o, in + chunks[k].in_off, n);
+            o += n;
+        }
+    }
+    SNAPPY_HIP_TRY(hipStreamSynchronize(s.stream));
+    return SNAPPY_OK;
+}

@@ -126,3 +126,46 @@ def mcdf_decode_and_hash_batch(streams, n_files_cap: int = 4096):
                     "payload_len": int(plen[a])})
         at += k
     return out
+
+
+def lz4net_encode(data, block_size: int = 0) -> bytes:
+    """The lz4net LZ4Stream (compress) framing of `data`, blocks compressed on the GPU
+    (block_size 0 = lz4net's default of 1 MiB).  Inverse of lz4net_decode."""
+    buf = _as_u8(data)
+    lib = native.lib()
+    bound = ctypes.c_uint64(0)
+    native.check(lib.snappy_lz4net_encode_bound(buf.size, block_size, ctypes.byref(bound)),
+                 "snappy_lz4net_encode_bound")
+    out = np.zeros(max(bound.value, 1), dtype=np.uint8)
+    n = ctypes.c_uint64(0)
+    native.check(lib.snappy_lz4net_encode(buf.ctypes.data if buf.size else None, buf.size, block_size,
+                                          out.ctypes.data, bound.value, ctypes.byref(n)),
+                 "snappy_lz4net_encode")
+    return out[: n.value].tobytes()
+
+
+def mcdf_write_header(files, description="", glamourer_data="", customize_plus_data="",
+                      manipulation_data="") -> bytes:
+    """McdfHeader.WriteToStream: "MCDF", version, length, compact JSON.  `files` is a list of
+    (game_paths, length) pairs."""
+    flat = [p.encode("utf-8") for paths, _ in files for p in paths]
+    arr = (ctypes.c_char_p * max(len(flat), 1))(*flat)
+    per = np.array([len(paths) for paths, _ in files] or [0], dtype=np.uint32)
+    lens = np.array([length for _, length in files] or [0], dtype=np.int64)
+    lib = native.lib()
+    n = ctypes.c_uint64(0)
+    args = (description.encode("utf-8"), glamourer_data.encode("utf-8"), customize_plus_data.encode("utf-8"),
+            manipulation_data.encode("utf-8"), arr, per.ctypes.data, lens.ctypes.data, len(files))
+    st = lib.snappy_mcdf_write_header(*args, None, 0, ctypes.byref(n))
+    if st not in (0, native.E_CAPACITY):
+        native.check(st, "snappy_mcdf_write_header")
+    out = np.zeros(max(n.value, 1), dtype=np.uint8)
+    native.check(lib.snappy_mcdf_write_header(*args, out.ctypes.data, out.size, ctypes.byref(n)),
+                 "snappy_mcdf_write_header")
+    return out[: n.value].tobytes()
+
+
+def write_mcdf(files, bodies, block_size: int = 0, **header_fields) -> bytes:
+    """A whole archive: header (lengths taken from the bodies) + file bodies, lz4net-framed."""
+    head = mcdf_write_header([(paths, len(body)) for paths, body in zip(files, bodies)], **header_fields)
+    return lz4net_encode(head + b"".join(bytes(b) for b in bodies), block_size)

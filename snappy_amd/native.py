@@ -58,6 +58,10 @@ SYMBOLS = [
     ("snappy_mcdf_decode_and_hash_batch", _i, [_u64, _vp, _vp, _vp, _vp, _u64, _vp, _vp, _vp, _vp]),
     ("snappy_store_files", _i, [_vp, _u64, ctypes.c_char_p, _vp, _vp]),
     ("snappy_mcdf_import_to_dir", _i, [ctypes.c_char_p, ctypes.c_char_p, _vp, _u64]),
+    ("snappy_mcdf_write_header", _i, [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p,
+                                      _vp, _vp, _vp, _u64, _vp, _u64, _u64p]),
+    ("snappy_lz4net_encode_bound", _i, [_u64, ctypes.c_uint32, _u64p]),
+    ("snappy_lz4net_encode", _i, [_vp, _u64, ctypes.c_uint32, _vp, _u64, _u64p]),
     ("snappy_profile_enable", None, [_i]),
     ("snappy_profile_last_ms", ctypes.c_float, [_i]),
     ("snappy_sha1_last_plan", _i, [ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_double)]),

@@ -134,3 +134,30 @@ def test_invalid_arguments(snappy):
     assert L.snappy_sha1_batch(None, None, None, 3, None) == snappy.native.E_INVALID_ARG
     assert L.snappy_lz4net_decoded_size(None, 4, None) == snappy.native.E_INVALID_ARG
     assert L.snappy_digests_to_hex(None, 0, None) == snappy.native.OK
+
+
+def test_mcdf_write_header_is_compact_json_in_declaration_order(snappy, oracle):
+    """McdfHeader.WriteToStream + JsonConvert.SerializeObject: host only, no GPU needed."""
+    import json
+    import struct
+
+    files = [(["chara/a.tex", "chara/B.tex"], 12345), ([], 0), (['q"uote\\back\n.mdl'], 2 ** 40)]
+    head = snappy.mcdf_write_header(files, description="d\u00e9sc \t tab", glamourer_data="g",
+                                    customize_plus_data="", manipulation_data="m")
+    assert head[:5] == b"MCDF\x01"
+    (n,) = struct.unpack_from("<i", head, 5)
+    assert len(head) == 9 + n
+    text = head[9:].decode("utf-8")
+    want = json.dumps({"Description": "d\u00e9sc \t tab", "GlamourerData": "g", "CustomizePlusData": "",
+                       "ManipulationData": "m",
+                       "Files": [{"GamePaths": p, "Length": ln} for p, ln in files]},
+                      separators=(",", ":"), ensure_ascii=False)
+    assert text == want
+    # and the reader takes it back
+    lengths, body = snappy.mcdf_parse_header(head + b"xyz")
+    assert list(lengths) == [12345, 0, 2 ** 40] and body == len(head)
+    version, parsed, body_offset = oracle.mcdf_parse_header(head)
+    assert version == 1 and body_offset == len(head)
+    assert parsed["Files"] == [(p, ln) for p, ln in files]
+    empty = snappy.mcdf_write_header([])
+    assert empty[9:] == b'{"Description":"","GlamourerData":"","CustomizePlusData":"","ManipulationData":"","Files":[]}'

@@ -276,3 +276,24 @@ def test_page_locked_sources(snappy, oracle):
         assert L.snappy_host_free(ptr) == 0
     assert L.snappy_host_alloc(0, ctypes.byref(ptr)) == 0 and not ptr.value
     assert L.snappy_host_free(None) == 0
+
+
+def test_offsets_beyond_4_gib(snappy, oracle):
+    """64-bit offset arithmetic: files that lie past the 4 GiB and 8 GiB marks of a 9 GiB buffer."""
+    import torch
+
+    size = 9 << 30
+    dev = torch.empty(size, dtype=torch.uint8, device="cuda")
+    rng = np.random.default_rng(81)
+    marks = [0, (4 << 30) - 1000, (4 << 30) + 2003, (8 << 30) - 7, size - 300_000]   # disjoint ranges
+    lengths = np.array([5000, 2001, 70_000, 14, 300_000], dtype=np.uint64)
+    offsets = np.array(marks, dtype=np.uint64)
+    want = []
+    for off, n in zip(marks, lengths):
+        blob = rng.integers(0, 256, size=int(n), dtype=np.uint8)
+        dev[off: off + int(n)] = torch.from_numpy(blob).cuda()
+        want.append(oracle.sha1(blob.tobytes()))
+    for path in ALL_PATHS + (None,):
+        force_path(path)
+        got = snappy.sha1_batch_device(0, dev.data_ptr(), offsets, lengths)
+        assert [g.tobytes() for g in got] == want, path
