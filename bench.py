@@ -146,11 +146,12 @@ def asset_like_bytes(n: int, rng: np.random.Generator) -> np.ndarray:
 
 def make_mcdf_archive(payload_bytes: int, n_files: int, rng: np.random.Generator, tag: str):
     """One synthetic MCDF archive: header JSON + file bodies, lz4net-framed in 1 MiB chunks
-    by the oracle's encoder.  Returns (stream bytes as uint8 array, decoded payload size)."""
+    by the library's own compressor (snappy_lz4net_encode).  Returns (stream bytes as uint8
+    array, decoded payload size, payload)."""
     import json as _json
     import struct
 
-    from oracle import oracle
+    from snappy_amd import native
 
     cuts = np.sort(rng.integers(0, payload_bytes, size=n_files - 1))
     sizes = np.diff(np.concatenate([[0], cuts, [payload_bytes]])).astype(np.int64)
@@ -160,11 +161,14 @@ def make_mcdf_archive(payload_bytes: int, n_files: int, rng: np.random.Generator
     head = b"MCDF\x01" + struct.pack("<i", len(js)) + js
     body = asset_like_bytes(payload_bytes, rng)
     payload = np.concatenate([np.frombuffer(head, dtype=np.uint8), body])
-    L = oracle.lib()
-    cap = L.oracle_lz4net_encode_bound(payload.size, 1 << 20)
-    out = np.empty(cap, dtype=np.uint8)
-    w = L.oracle_lz4net_encode(payload.ctypes.data, payload.size, out.ctypes.data, cap, 1 << 20, 1)
-    return out[:w].copy(), int(payload.size), payload
+    L = native.lib()
+    cap = ctypes.c_uint64(0)
+    native.check(L.snappy_lz4net_encode_bound(payload.size, 1 << 20, ctypes.byref(cap)), "encode bound")
+    out = np.empty(cap.value, dtype=np.uint8)
+    w = ctypes.c_uint64(0)
+    native.check(L.snappy_lz4net_encode(payload.ctypes.data, payload.size, 1 << 20, out.ctypes.data, out.size,
+                                        ctypes.byref(w)), "snappy_lz4net_encode")
+    return out[: w.value].copy(), int(payload.size), payload
 
 
 def run_mcdf(args, rank, world, local_rank, dist):
@@ -255,7 +259,9 @@ def run_mcdf(args, rank, world, local_rank, dist):
                    "compressed_bytes_per_gpu": comp_bytes, "decoded_bytes_per_gpu": out_bytes,
                    "ratio": out_bytes / comp_bytes},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "lz4_decode_kernel",
+                     "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": measured_traffic("mcdf", 1.0) if (n_arch, args.archive_mib) == (8, 256.0) else None,
+                     "kernel": "lz4_decode_kernel",
                      "kernel_ms": k_lz4, "algorithmic_bytes_per_launch": algo,
                      "sha1_kernel_ms": float(np.mean(sha_ms))},
         "digests_match_hashlib_sample": bool(ok),
@@ -448,10 +454,10 @@ def end_to_end(lib, native, torch, buf, offsets, lengths, total_bytes, digests, 
 def dry_run(args, rank, world):
     """The N-rank control flow of main() without a GPU: per-rank corpus, barrier, timed steps,
     MAX of the times and SUM of the bytes over ranks, one JSON line from rank 0."""
+    import hashlib
+
     import torch
     import torch.distributed as dist
-
-    from oracle import oracle
 
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -466,7 +472,8 @@ def dry_run(args, rank, world):
         dist.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        digests = oracle.sha1_batch_np(base, offsets, lengths)
+        # hashlib stands in for the kernels: this mode only exercises the rank plumbing
+        digests = [hashlib.sha1(base[int(o): int(o + n)].tobytes()).digest() for o, n in zip(offsets, lengths)]
     elapsed = time.perf_counter() - t0
     job_bytes = float(lengths.sum())
     if world > 1:
@@ -481,7 +488,7 @@ def dry_run(args, rank, world):
                           "scaling": "strong" if args.strong and world > 1 else "weak",
                           "value": job_bytes * args.steps / elapsed / GB, "unit": "GB/s",
                           "job_bytes": job_bytes, "files_rank0": int(len(lengths)),
-                          "digest0": digests[0].tobytes().hex()}), flush=True)
+                          "digest0": digests[0].hex()}), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -526,7 +533,7 @@ def main():
                          "rank has a corpus of its own, weak scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-dry-run", action="store_true",
-                    help="no GPU: exercise the multi-rank plumbing with the CPU oracle standing in for the "
+                    help="no GPU: exercise the multi-rank plumbing with hashlib standing in for the "
                          "kernels on a tiny corpus (used by the gloo test; the numbers mean nothing)")
     ap.add_argument("--cpu-sample-gb", type=float, default=4.0)
     ap.add_argument("--no-extra", action="store_true",
