@@ -112,8 +112,8 @@ __device__ __forceinline__ void store_piece(uint8_t *dst, uint32_t vec, const Pi
     reinterpret_cast<uint4 *>(dst)[vec] = o;
 }
 
-__device__ __forceinline__ void copy_long(uint8_t *dst, const uint8_t *src, uint32_t n,
-                                          uint32_t lane)
+__device__ __forceinline__ void copy_long(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src,
+                                          uint32_t n, uint32_t lane)
 {
     const uint32_t head = (16u - static_cast<uint32_t>(reinterpret_cast<uintptr_t>(dst) & 15u)) & 15u;
     if (head) {
@@ -127,16 +127,35 @@ __device__ __forceinline__ void copy_long(uint8_t *dst, const uint8_t *src, uint
     const uint32_t *s = reinterpret_cast<const uint32_t *>(src - shift);
     const uint32_t n_vec = n >> 4;
     uint32_t k = lane;
+    // Software pipeline, 4 KiB per step: the loads of step i+1 are issued before
+    // the stores of step i.  Loads and stores share one in-order counter on this
+    // hardware, so a load issued behind a store cannot be waited for without
+    // waiting for the store as well; issued ahead of it, it can.
+    if (k + 3u * kWave < n_vec) {
+        Piece a = load_piece(s, k, shift);
+        Piece b = load_piece(s, k + kWave, shift);
+        Piece c = load_piece(s, k + 2u * kWave, shift);
+        Piece d = load_piece(s, k + 3u * kWave, shift);
 #pragma clang loop vectorize(disable) unroll(disable)
-    for (; k + 3u * kWave < n_vec; k += 4u * kWave) {
-        const Piece a = load_piece(s, k, shift);
-        const Piece b = load_piece(s, k + kWave, shift);
-        const Piece c = load_piece(s, k + 2u * kWave, shift);
-        const Piece d = load_piece(s, k + 3u * kWave, shift);
+        for (; k + 7u * kWave < n_vec; k += 4u * kWave) {
+            const Piece a2 = load_piece(s, k + 4u * kWave, shift);
+            const Piece b2 = load_piece(s, k + 5u * kWave, shift);
+            const Piece c2 = load_piece(s, k + 6u * kWave, shift);
+            const Piece d2 = load_piece(s, k + 7u * kWave, shift);
+            store_piece(dst, k, a, shift);
+            store_piece(dst, k + kWave, b, shift);
+            store_piece(dst, k + 2u * kWave, c, shift);
+            store_piece(dst, k + 3u * kWave, d, shift);
+            a = a2;
+            b = b2;
+            c = c2;
+            d = d2;
+        }
         store_piece(dst, k, a, shift);
         store_piece(dst, k + kWave, b, shift);
         store_piece(dst, k + 2u * kWave, c, shift);
         store_piece(dst, k + 3u * kWave, d, shift);
+        k += 4u * kWave;
     }
 #pragma clang loop vectorize(disable) unroll(disable)
     for (; k < n_vec; k += kWave)
@@ -160,8 +179,7 @@ __device__ __forceinline__ void copy_run(uint8_t *dst, const uint8_t *src, uint3
 // Overlapping match: the output repeats the `period` bytes that end at dst.
 // The first `span` bytes (a multiple of the period, at least kPeriodSpan) are
 // written as dst[i] = dst[i mod period - period], which reads only bytes that
-// existed before the match; the rest repeats with distance `span`, a plain
-// forward copy in pieces of `span` bytes, each piece reading the one before.
+// existed before the match; the rest is filled by doubling.
 constexpr uint32_t kPeriodSpan = 4096;
 
 __device__ __forceinline__ void copy_periodic(uint8_t *dst, uint32_t period, uint32_t n,
@@ -202,9 +220,13 @@ __device__ __forceinline__ void copy_periodic(uint8_t *dst, uint32_t period, uin
             r -= (r >= period) ? period : 0u;
         }
     }
-    for (uint32_t done = head; done < n; done += span) {
-        const uint32_t piece = (n - done < span) ? n - done : span;
-        copy_run(dst + done, dst + done - span, piece, lane);
+    // What has been written so far is a whole number of periods, so the next
+    // `done` bytes are a copy of the first `done`: the written part doubles with
+    // every step, and each step is one plain copy between disjoint ranges.
+    for (uint32_t done = head; done < n;) {
+        const uint32_t piece = (n - done < done) ? n - done : done;
+        copy_run(dst + done, dst, piece, lane);
+        done += piece;
     }
 }
 
