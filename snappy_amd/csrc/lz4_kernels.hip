@@ -127,35 +127,33 @@ __device__ __forceinline__ void copy_long(uint8_t *__restrict__ dst, const uint8
     const uint32_t *s = reinterpret_cast<const uint32_t *>(src - shift);
     const uint32_t n_vec = n >> 4;
     uint32_t k = lane;
-    // Software pipeline, 4 KiB per step: the loads of step i+1 are issued before
-    // the stores of step i.  Loads and stores share one in-order counter on this
-    // hardware, so a load issued behind a store cannot be waited for without
+    // Software pipeline, kDepth KiB per step: the loads of step i+1 are issued
+    // before the stores of step i.  Loads and stores share one in-order counter on
+    // this hardware, so a load issued behind a store cannot be waited for without
     // waiting for the store as well; issued ahead of it, it can.
-    if (k + 3u * kWave < n_vec) {
-        Piece a = load_piece(s, k, shift);
-        Piece b = load_piece(s, k + kWave, shift);
-        Piece c = load_piece(s, k + 2u * kWave, shift);
-        Piece d = load_piece(s, k + 3u * kWave, shift);
+    constexpr uint32_t kDepth = 8;
+    if (k + (kDepth - 1u) * kWave < n_vec) {
+        Piece cur[kDepth];
+#pragma unroll
+        for (uint32_t j = 0; j < kDepth; ++j)
+            cur[j] = load_piece(s, k + j * kWave, shift);
 #pragma clang loop vectorize(disable) unroll(disable)
-        for (; k + 7u * kWave < n_vec; k += 4u * kWave) {
-            const Piece a2 = load_piece(s, k + 4u * kWave, shift);
-            const Piece b2 = load_piece(s, k + 5u * kWave, shift);
-            const Piece c2 = load_piece(s, k + 6u * kWave, shift);
-            const Piece d2 = load_piece(s, k + 7u * kWave, shift);
-            store_piece(dst, k, a, shift);
-            store_piece(dst, k + kWave, b, shift);
-            store_piece(dst, k + 2u * kWave, c, shift);
-            store_piece(dst, k + 3u * kWave, d, shift);
-            a = a2;
-            b = b2;
-            c = c2;
-            d = d2;
+        for (; k + (2u * kDepth - 1u) * kWave < n_vec; k += kDepth * kWave) {
+            Piece nxt[kDepth];
+#pragma unroll
+            for (uint32_t j = 0; j < kDepth; ++j)
+                nxt[j] = load_piece(s, k + (kDepth + j) * kWave, shift);
+#pragma unroll
+            for (uint32_t j = 0; j < kDepth; ++j)
+                store_piece(dst, k + j * kWave, cur[j], shift);
+#pragma unroll
+            for (uint32_t j = 0; j < kDepth; ++j)
+                cur[j] = nxt[j];
         }
-        store_piece(dst, k, a, shift);
-        store_piece(dst, k + kWave, b, shift);
-        store_piece(dst, k + 2u * kWave, c, shift);
-        store_piece(dst, k + 3u * kWave, d, shift);
-        k += 4u * kWave;
+#pragma unroll
+        for (uint32_t j = 0; j < kDepth; ++j)
+            store_piece(dst, k + j * kWave, cur[j], shift);
+        k += kDepth * kWave;
     }
 #pragma clang loop vectorize(disable) unroll(disable)
     for (; k < n_vec; k += kWave)
