@@ -228,9 +228,67 @@ __device__ __forceinline__ void copy_periodic(uint8_t *dst, uint32_t period, uin
     }
 }
 
+// Short sequences.  A copy through global memory costs a memory round trip (and a
+// match that reads what the previous sequence wrote also waits for that write),
+// about a microsecond per sequence whatever its length; real LZ4 streams are
+// mostly sequences of tens of bytes.  So short literal runs are taken from the
+// input window the wave already holds in registers, and every short piece of
+// output is also written to a ring of the wave's most recent kHist output bytes
+// in LDS, from which short matches read.  The ring holds the output positions
+// [valid_from, op); long copies bypass it and reset valid_from.
+constexpr uint32_t kHist = 8192;       // bytes of recent output per wave in LDS
+constexpr uint32_t kShortLit = 192;    // longest literal run served from the window registers
+constexpr uint32_t kShortMatch = 512;  // longest match served from the ring
+
+__device__ __forceinline__ void emit_short_literals(const InputWindow &win, uint32_t ip,
+                                                    uint32_t lit, uint8_t *out, uint8_t *ring,
+                                                    uint32_t op, uint32_t lane)
+{
+    // The caller has made sure the window covers [ip, ip + lit).
+    for (uint32_t base = 0; base < lit; base += kWave) {
+        const uint32_t i = base + lane;
+        const bool on = i < lit;
+        const uint32_t pos = ip + (on ? i : 0u);
+        const uint32_t from_lane = (pos >> 2) - win.first_dword;
+        const uint32_t word = static_cast<uint32_t>(
+            __builtin_amdgcn_ds_bpermute(static_cast<int>(from_lane << 2), static_cast<int>(win.dword)));
+        const uint8_t byte = static_cast<uint8_t>(word >> ((pos & 3u) * 8u));
+        if (on) {
+            out[op + i] = byte;
+            ring[(op + i) & (kHist - 1u)] = byte;
+        }
+    }
+}
+
+__device__ __forceinline__ void emit_short_match(uint8_t *out, uint8_t *ring, uint32_t op,
+                                                 uint32_t offset, uint32_t ml, uint32_t lane)
+{
+    const uint32_t src0 = op - offset;
+    const bool overlapping = offset < ml;
+    // i mod offset for i < 1024: exact in float up to one step either way.
+    const float inv = 1.0f / static_cast<float>(offset);
+    for (uint32_t base = 0; base < ml; base += kWave) {
+        const uint32_t i = base + lane;
+        uint32_t k = i;
+        if (overlapping) {
+            const uint32_t q = static_cast<uint32_t>(static_cast<float>(i) * inv);
+            k = i - q * offset;
+            k += (static_cast<int32_t>(k) < 0) ? offset : 0u;
+            k -= (k >= offset) ? offset : 0u;
+        }
+        // The pattern [src0, src0 + offset) lies before op and, offset + ml being
+        // at most kHist, is not overwritten by this match's own ring writes.
+        const uint8_t byte = ring[(src0 + k) & (kHist - 1u)];
+        if (i < ml) {
+            out[op + i] = byte;
+            ring[(op + i) & (kHist - 1u)] = byte;
+        }
+    }
+}
+
 // Decodes one compressed chunk; returns true when the block is well-formed.
 __device__ bool decode_block(const uint8_t *__restrict__ in_base, uint64_t in_alloc,
-                             const Lz4Chunk &ck, uint8_t *out_base, uint32_t lane)
+                             const Lz4Chunk &ck, uint8_t *out_base, uint8_t *ring, uint32_t lane)
 {
     const uint8_t *src = in_base + ck.in_off;
     uint8_t *dst = out_base + ck.out_off;
@@ -246,6 +304,7 @@ __device__ bool decode_block(const uint8_t *__restrict__ in_base, uint64_t in_al
 
     uint32_t ip = in_shift;  // uniform
     uint32_t op = 0;         // uniform
+    uint32_t valid_from = 0; // uniform: the ring holds output positions [valid_from, op)
     const uint8_t *src_al = src - in_shift;
 
     for (;;) {
@@ -285,8 +344,14 @@ __device__ bool decode_block(const uint8_t *__restrict__ in_base, uint64_t in_al
         const bool last = (op + lit + kCopyLength > oend);
         if (last && op + lit != oend)
             return false;
-        if (lit)
+        if (lit != 0u && lit <= kShortLit) {
+            if ((ip >> 2) < win.first_dword || ((ip + lit + 3u) >> 2) > win.first_dword + 64u)
+                win.fill(ip >> 2, lane);
+            emit_short_literals(win, ip, lit, dst, ring, op, lane);
+        } else if (lit != 0u) {
             copy_run(dst + op, src_al + ip, lit, lane);
+            valid_from = op + lit;
+        }
         ip += lit;
         op += lit;
         if (last)
@@ -330,12 +395,17 @@ __device__ bool decode_block(const uint8_t *__restrict__ in_base, uint64_t in_al
         if (ml > oend - op || op + ml + kLastLiterals > oend)
             return false;
 
-        uint8_t *mdst = dst + op;
-        const uint8_t *msrc = mdst - offset;
-        if (offset >= ml) {
-            copy_run(mdst, msrc, ml, lane);
+        if (ml <= kShortMatch && offset <= kHist - kShortMatch && op - offset >= valid_from) {
+            emit_short_match(dst, ring, op, offset, ml, lane);
         } else {
-            copy_periodic(mdst, offset, ml, lane);
+            uint8_t *mdst = dst + op;
+            const uint8_t *msrc = mdst - offset;
+            if (offset >= ml) {
+                copy_run(mdst, msrc, ml, lane);
+            } else {
+                copy_periodic(mdst, offset, ml, lane);
+            }
+            valid_from = op + ml;
         }
         op += ml;
     }
@@ -346,7 +416,9 @@ lz4_decode_kernel(const uint8_t *__restrict__ in_base, uint64_t in_alloc, uint8_
                   const Lz4Chunk *__restrict__ chunks, uint32_t n_chunks,
                   uint32_t *__restrict__ queue, uint32_t *__restrict__ status)
 {
+    __shared__ uint8_t rings[4][kHist];
     const uint32_t lane = threadIdx.x & (kWave - 1);
+    uint8_t *ring = rings[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)];
     for (;;) {
         const uint32_t i = wave_claim(queue, 1u, lane);
         if (i >= n_chunks)
@@ -354,7 +426,7 @@ lz4_decode_kernel(const uint8_t *__restrict__ in_base, uint64_t in_alloc, uint8_
         const Lz4Chunk ck = chunks[i];
         bool ok = true;
         if (ck.compressed) {
-            ok = decode_block(in_base, in_alloc, ck, out_base, lane);
+            ok = decode_block(in_base, in_alloc, ck, out_base, ring, lane);
         } else {
             copy_run(out_base + ck.out_off, in_base + ck.in_off, ck.orig_len, lane);
         }
