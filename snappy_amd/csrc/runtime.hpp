@@ -66,7 +66,6 @@ struct DeviceCtx {
     std::mutex mu;
     std::condition_variable cv;
     std::vector<std::unique_ptr<Slot>> slots;
-    std::atomic<bool> overlap_busy{false};  // a kernel that waits for its transfer is running
 };
 
 // RAII lease of a slot; sets the HIP device for the calling thread.

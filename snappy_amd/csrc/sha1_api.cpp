@@ -264,6 +264,7 @@ hipError_t transfer_direct(Slot &s, const std::vector<Piece> &pieces, uint64_t s
 // calling thread sends each filled buffer on in slice order and raises the
 // counter behind it.  Several memcpy threads are what it takes to keep up with
 // the PCIe link.
+constexpr int kMaxHipDevices = 64;
 constexpr unsigned kRingSlots = 6;
 constexpr unsigned kStageThreads = 6;
 
@@ -517,12 +518,14 @@ int hash_ranges_on_device(int device, const HostRange *ranges, uint64_t first, u
         256, static_cast<uint64_t>(env_long("SNAPPY_OVERLAP_SLICE_BYTES", 32L << 20)) & ~uint64_t(255));
     if (lease.slot->d_flags == nullptr || total < min_bytes)
         return hash_ranges_serial(lease, ranges, first, n, digests);
-    // One waiting kernel per device at a time, for the same reason: a second
+    // One waiting kernel per physical GPU at a time, for the same reason: a second
     // caller copies first and hashes afterwards.
-    if (lease.dev->overlap_busy.exchange(true))
+    static std::atomic<bool> waiting_kernel[kMaxHipDevices];
+    std::atomic<bool> &busy = waiting_kernel[lease.dev->hip_device % kMaxHipDevices];
+    if (busy.exchange(true))
         return hash_ranges_serial(lease, ranges, first, n, digests);
     st = hash_ranges_overlapped(lease, ranges, first, n, slice, digests);
-    lease.dev->overlap_busy.store(false);
+    busy.store(false);
     return st;
 }
 
