@@ -19,7 +19,7 @@ SOURCES = [
     "sha1_kernels.hip",
     "sha1_plan.hip",
     "lz4_kernels.hip", "lz4_encode.hip",
-    "runtime.cpp",
+    "runtime.cpp", "transfer.cpp",
     "sha1_api.cpp",
     "lz4net_host.cpp",
     "mcdf_host.cpp",

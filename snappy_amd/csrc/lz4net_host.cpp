@@ -13,6 +13,7 @@
 //             stored bytes
 //   end     : EOF exactly at a chunk boundary
 #include "lz4net_host.hpp"
+#include "transfer.hpp"
 
 #include <algorithm>
 #include <cstring>
@@ -137,12 +138,12 @@ int decode_streams_on_device(SlotLease &lease, std::vector<StreamJob> &jobs)
     hipStream_t stream = s.stream;
     Lz4Chunk *table = static_cast<Lz4Chunk *>(s.h_stage.ptr);
     uint64_t k = 0;
+    std::vector<Piece> pieces;
     for (StreamJob &j : jobs) {
         const uint64_t region = (j.in_len + 256 + 255) & ~uint64_t(255);
         SNAPPY_HIP_TRY(hipMemsetAsync(arena + j.in_off + j.in_len, 0, region - j.in_len, stream));
         if (j.in_len)
-            SNAPPY_HIP_TRY(hipMemcpyAsync(arena + j.in_off, j.in, j.in_len, hipMemcpyHostToDevice,
-                                          stream));
+            pieces.push_back({j.in, j.in_off, j.in_len});
         for (const Lz4Chunk &c : j.layout.chunks) {
             table[k] = c;
             table[k].in_off += j.in_off;
@@ -153,6 +154,10 @@ int decode_streams_on_device(SlotLease &lease, std::vector<StreamJob> &jobs)
     SNAPPY_HIP_TRY(hipMemcpyAsync(s.d_tasks.ptr, s.h_stage.ptr, table_bytes, hipMemcpyHostToDevice,
                                   stream));
     SNAPPY_HIP_TRY(hipMemsetAsync(s.d_misc.ptr, 0, 256, stream));
+    // The compressed streams travel on the copy stream (through the page-locked ring
+    // when they lie in ordinary memory); the call returns when they have landed.
+    SNAPPY_HIP_TRY(transfer_to_device(s, lease.dev->hip_device, pieces, kTransferSliceBytes, arena,
+                                      nullptr, nullptr));
 
     const bool prof = profiling_enabled();
     if (prof)
@@ -328,7 +333,11 @@ extern "C" int snappy_lz4net_encode(const uint8_t *in, uint64_t in_len, uint32_t
     uint8_t *d_base = static_cast<uint8_t *>(s.d_data.ptr);
     Lz4EncChunk *d_chunks = static_cast<Lz4EncChunk *>(s.d_tasks.ptr);
     uint32_t *d_sizes = static_cast<uint32_t *>(s.d_out.ptr);
-    SNAPPY_HIP_TRY(hipMemcpyAsync(d_base, in, in_len, hipMemcpyHostToDevice, s.stream));
+    {
+        std::vector<Piece> pieces{{in, 0, in_len}};
+        SNAPPY_HIP_TRY(transfer_to_device(s, lease.dev->hip_device, pieces, kTransferSliceBytes, d_base,
+                                          nullptr, nullptr));
+    }
     SNAPPY_HIP_TRY(hipMemcpyAsync(d_chunks, chunks.data(), n_chunks * sizeof(Lz4EncChunk),
                                   hipMemcpyHostToDevice, s.stream));
     const bool prof = profiling_enabled();

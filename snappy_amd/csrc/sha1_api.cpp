@@ -6,6 +6,7 @@
 // 62-86).  All hashing runs in the HIP kernels of sha1_kernels.hip; there is no
 // host implementation of SHA-1 in this library.
 #include "sha1_api.hpp"
+#include "transfer.hpp"
 
 #include <algorithm>
 #include <cstddef>
@@ -166,11 +167,6 @@ struct HostRange {
     uint64_t len;
 };
 
-struct Piece {
-    const uint8_t *src;
-    uint64_t dst, len;
-};
-
 // Lays the ranges [first, first + n) out in the device arena in the order
 // `order` (indices relative to first).  Ranges that follow each other both in
 // that order and in host memory keep their relative layout and move as one
@@ -217,196 +213,10 @@ int hash_ranges_serial(SlotLease &lease, const HostRange *ranges, uint64_t first
     if ((st = s.d_data.ensure(static_cast<size_t>(bytes) + 64)) != SNAPPY_OK)
         return st;
     uint8_t *d_base = static_cast<uint8_t *>(s.d_data.ptr);
-    for (const Piece &c : pieces)
-        SNAPPY_HIP_TRY(hipMemcpyAsync(d_base + c.dst, c.src, c.len, hipMemcpyHostToDevice,
-                                      s.stream));
+    SNAPPY_HIP_TRY(transfer_to_device(s, lease.dev->hip_device, pieces, kTransferSliceBytes, d_base,
+                                      nullptr, nullptr));
     return run_sha1_tables(lease, d_base, dev_off.data(), lens.data(), n, digests + 20 * first,
                            nullptr);
-}
-
-// Moves the pieces to the device in arena order on the slot's copy stream, cut at
-// slice boundaries, and raises the arrival counter after every complete slice.
-// Direct form: the sources are page-locked, every copy is a DMA from where the
-// bytes lie.
-hipError_t transfer_direct(Slot &s, const std::vector<Piece> &pieces, uint64_t slice_bytes,
-                           uint64_t n_slices, uint8_t *d_base, Sha1Arrival *d_arrival,
-                           const uint32_t *slice_numbers)
-{
-    hipError_t e = hipSuccess;
-    uint64_t next_mark = 1;  // slice whose end has not been marked yet
-    for (const Piece &c : pieces) {
-        uint64_t done = 0;
-        while (done < c.len && e == hipSuccess) {
-            const uint64_t pos = c.dst + done;
-            const uint64_t slice_end = (pos / slice_bytes + 1) * slice_bytes;
-            const uint64_t take = std::min<uint64_t>(c.len - done, slice_end - pos);
-            e = hipMemcpyAsync(d_base + pos, c.src + done, take, hipMemcpyHostToDevice,
-                               s.copy_stream);
-            done += take;
-            // Every slice that ends at or before this position is complete.
-            const uint64_t complete = (c.dst + done) / slice_bytes;
-            while (e == hipSuccess && next_mark <= complete) {
-                e = hipMemcpyAsync(&d_arrival->arrived, &slice_numbers[next_mark - 1],
-                                   sizeof(uint32_t), hipMemcpyHostToDevice, s.copy_stream);
-                ++next_mark;
-            }
-        }
-        if (e != hipSuccess)
-            return e;
-    }
-    // The last, partial slice (and any gap slices before it).
-    return hipMemcpyAsync(&d_arrival->arrived, &slice_numbers[n_slices - 1], sizeof(uint32_t),
-                          hipMemcpyHostToDevice, s.copy_stream);
-}
-
-// Staged form for ordinary (pageable) sources, which no DMA engine can read:
-// worker threads copy slice after slice into a ring of page-locked buffers, the
-// calling thread sends each filled buffer on in slice order and raises the
-// counter behind it.  Several memcpy threads are what it takes to keep up with
-// the PCIe link.
-constexpr int kMaxHipDevices = 64;
-constexpr unsigned kRingSlots = 6;
-constexpr unsigned kStageThreads = 6;
-
-hipError_t transfer_staged(Slot &s, int hip_device, const std::vector<Piece> &pieces,
-                           uint64_t slice_bytes, uint64_t n_slices, uint8_t *d_base,
-                           Sha1Arrival *d_arrival, const uint32_t *slice_numbers)
-{
-    struct Segment {
-        const uint8_t *src;
-        uint64_t dst, len;
-    };
-    std::vector<Segment> segs;
-    std::vector<size_t> seg_begin(n_slices + 1, 0);
-    for (const Piece &c : pieces) {
-        uint64_t done = 0;
-        while (done < c.len) {
-            const uint64_t pos = c.dst + done;
-            const uint64_t slice = pos / slice_bytes;
-            const uint64_t take = std::min<uint64_t>(c.len - done, (slice + 1) * slice_bytes - pos);
-            segs.push_back({c.src + done, pos, take});
-            ++seg_begin[slice + 1];
-            done += take;
-        }
-    }
-    for (uint64_t k = 0; k < n_slices; ++k)
-        seg_begin[k + 1] += seg_begin[k];
-
-    if (s.h_ring.ensure(static_cast<size_t>(kRingSlots * slice_bytes)) != SNAPPY_OK)
-        return hipErrorOutOfMemory;
-    uint8_t *ring = static_cast<uint8_t *>(s.h_ring.ptr);
-    hipEvent_t sent[kRingSlots] = {};
-    for (unsigned r = 0; r < kRingSlots; ++r)
-        if (hipEventCreateWithFlags(&sent[r], hipEventDisableTiming) != hipSuccess) {
-            for (unsigned q = 0; q < r; ++q)
-                (void)hipEventDestroy(sent[q]);
-            return hipErrorOutOfMemory;
-        }
-
-    std::mutex mu;
-    std::condition_variable cv;
-    std::vector<char> filled(n_slices, 0);
-    uint64_t issued = 0;  // slices handed to the copy stream (their ring event is recorded)
-    bool failed = false;
-    std::atomic<uint64_t> next_fill{0};
-
-    auto fill = [&] {
-        (void)hipSetDevice(hip_device);
-        for (;;) {
-            const uint64_t k = next_fill.fetch_add(1);
-            if (k >= n_slices)
-                return;
-            if (k >= kRingSlots) {  // the ring slot's previous content must have left
-                std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return failed || issued > k - kRingSlots; });
-                if (failed)
-                    return;
-                lk.unlock();
-                if (hipEventSynchronize(sent[k % kRingSlots]) != hipSuccess) {
-                    std::lock_guard<std::mutex> g(mu);
-                    failed = true;
-                    cv.notify_all();
-                    return;
-                }
-            }
-            uint8_t *slot = ring + (k % kRingSlots) * slice_bytes;
-            for (size_t q = seg_begin[k]; q < seg_begin[k + 1]; ++q)
-                std::memcpy(slot + (segs[q].dst - k * slice_bytes), segs[q].src, segs[q].len);
-            {
-                std::lock_guard<std::mutex> g(mu);
-                filled[k] = 1;
-            }
-            cv.notify_all();
-        }
-    };
-    const unsigned n_threads = static_cast<unsigned>(std::min<uint64_t>(
-        n_slices, std::min<unsigned>(kStageThreads, std::max(1u, std::thread::hardware_concurrency()))));
-    std::vector<std::thread> workers;
-    for (unsigned t = 0; t < n_threads; ++t)
-        workers.emplace_back(fill);
-
-    hipError_t e = hipSuccess;
-    for (uint64_t k = 0; k < n_slices && e == hipSuccess; ++k) {
-        {
-            std::unique_lock<std::mutex> lk(mu);
-            cv.wait(lk, [&] { return failed || filled[k]; });
-            if (failed) {
-                e = hipErrorUnknown;
-                break;
-            }
-        }
-        if (seg_begin[k + 1] > seg_begin[k]) {
-            const uint64_t lo = segs[seg_begin[k]].dst;
-            const Segment &last = segs[seg_begin[k + 1] - 1];
-            const uint64_t hi = last.dst + last.len;
-            e = hipMemcpyAsync(d_base + lo, ring + (k % kRingSlots) * slice_bytes + (lo - k * slice_bytes),
-                               hi - lo, hipMemcpyHostToDevice, s.copy_stream);
-        }
-        if (e == hipSuccess)
-            e = hipMemcpyAsync(&d_arrival->arrived, &slice_numbers[k], sizeof(uint32_t),
-                               hipMemcpyHostToDevice, s.copy_stream);
-        if (e == hipSuccess)
-            e = hipEventRecord(sent[k % kRingSlots], s.copy_stream);
-        {
-            std::lock_guard<std::mutex> g(mu);
-            if (e == hipSuccess)
-                issued = k + 1;
-            else
-                failed = true;
-        }
-        cv.notify_all();
-    }
-    {
-        std::lock_guard<std::mutex> g(mu);
-        if (e != hipSuccess)
-            failed = true;
-    }
-    cv.notify_all();
-    for (auto &w : workers)
-        w.join();
-    if (e == hipSuccess)
-        e = hipStreamSynchronize(s.copy_stream);  // the ring must not be reused before it has left
-    for (unsigned r = 0; r < kRingSlots; ++r)
-        (void)hipEventDestroy(sent[r]);
-    return e;
-}
-
-// True when every piece starts in memory that HIP knows as page-locked host
-// memory (snappy_host_alloc, hipHostMalloc, hipHostRegister).
-bool sources_are_page_locked(const std::vector<Piece> &pieces)
-{
-    if (pieces.size() > 4096)
-        return false;  // not worth a query per piece: staging is correct for any source
-    for (const Piece &c : pieces) {
-        hipPointerAttribute_t attr;
-        if (hipPointerGetAttributes(&attr, c.src) != hipSuccess) {
-            (void)hipGetLastError();
-            return false;
-        }
-        if (attr.type != hipMemoryTypeHost)
-            return false;
-    }
-    return true;
 }
 
 // Hash while copying.  The kernel is launched first; the data then follows on
@@ -468,13 +278,8 @@ int hash_ranges_overlapped(SlotLease &lease, const HostRange *ranges, uint64_t f
         return st;  // nothing was launched that waits
 
     // From here on a kernel may be waiting: whatever goes wrong, it has to be told.
-    hipError_t copy_error =
-        sources_are_page_locked(pieces) || env_long("SNAPPY_STAGE_PAGEABLE", 1) == 0
-            ? transfer_direct(s, pieces, slice_bytes, n_slices, d_base, d_arrival, slice_numbers)
-            : transfer_staged(s, lease.dev->hip_device, pieces, slice_bytes, n_slices, d_base,
-                              d_arrival, slice_numbers);
-    if (copy_error == hipSuccess)
-        copy_error = hipStreamSynchronize(s.copy_stream);
+    hipError_t copy_error = transfer_to_device(s, lease.dev->hip_device, pieces, slice_bytes, d_base,
+                                               &d_arrival->arrived, slice_numbers);
     if (copy_error != hipSuccess) {
         set_error_detail(std::string("host to device transfer: ") + hipGetErrorString(copy_error));
         (void)hipGetLastError();
@@ -495,6 +300,8 @@ int hash_ranges_overlapped(SlotLease &lease, const HostRange *ranges, uint64_t f
     finish_sha1_profile(lease);
     return SNAPPY_OK;
 }
+
+constexpr int kMaxHipDevices = 64;
 
 // Copies the ranges [first, last) into the slot's device arena and hashes them
 // on the slot's device.

@@ -1,0 +1,33 @@
+// Host -> device transfers of scattered host ranges ("pieces") into one device
+// arena, fast for both kinds of host memory: page-locked sources go by direct
+// DMA; ordinary (pageable) ones, which no DMA engine can read, through a ring of
+// page-locked buffers filled by several memcpy threads.  Optionally a progress
+// counter in device memory is raised after every slice of the arena, for
+// kernels that start before their input has arrived.
+#pragma once
+
+#include <vector>
+
+#include "runtime.hpp"
+
+namespace snappy {
+
+// len bytes at src go to arena offset dst.  Pieces are given in arena order.
+struct Piece {
+    const uint8_t *src;
+    uint64_t dst, len;
+};
+
+constexpr uint64_t kTransferSliceBytes = 32ull << 20;
+
+// Moves the pieces to d_base on the slot's copy stream and waits for them.
+// slice_bytes: granularity (a multiple of 256).  d_progress / slice_numbers (both
+// null, or both set): after slice k of the arena has landed, the 32-bit word
+// *d_progress is set to slice_numbers[k] == k + 1 (slice_numbers: page-locked
+// host memory with one entry per slice).  Small batches of pageable memory are
+// sent with plain copies.
+hipError_t transfer_to_device(Slot &s, int hip_device, const std::vector<Piece> &pieces,
+                              uint64_t slice_bytes, uint8_t *d_base, uint32_t *d_progress,
+                              const uint32_t *slice_numbers);
+
+}  // namespace snappy
