@@ -82,11 +82,13 @@ hipError_t transfer_staged(Slot &s, int hip_device, const std::vector<Piece> &pi
     for (uint64_t k = 0; k < n_slices; ++k)
         seg_begin[k + 1] += seg_begin[k];
 
-    if (s.h_ring.ensure(static_cast<size_t>(kRingSlots * slice_bytes)) != SNAPPY_OK)
+    // No more ring than the batch has slices (a small batch must not pin 192 MiB).
+    const unsigned ring_slots = static_cast<unsigned>(std::min<uint64_t>(kRingSlots, n_slices));
+    if (s.h_ring.ensure(static_cast<size_t>(ring_slots * slice_bytes)) != SNAPPY_OK)
         return hipErrorOutOfMemory;
     uint8_t *ring = static_cast<uint8_t *>(s.h_ring.ptr);
-    hipEvent_t sent[kRingSlots] = {};
-    for (unsigned r = 0; r < kRingSlots; ++r)
+    hipEvent_t sent[kRingSlots] = {};  // the first ring_slots are used
+    for (unsigned r = 0; r < ring_slots; ++r)
         if (hipEventCreateWithFlags(&sent[r], hipEventDisableTiming) != hipSuccess) {
             for (unsigned q = 0; q < r; ++q)
                 (void)hipEventDestroy(sent[q]);
@@ -106,20 +108,20 @@ hipError_t transfer_staged(Slot &s, int hip_device, const std::vector<Piece> &pi
             const uint64_t k = next_fill.fetch_add(1);
             if (k >= n_slices)
                 return;
-            if (k >= kRingSlots) {  // the ring slot's previous content must have left
+            if (k >= ring_slots) {  // the ring slot's previous content must have left
                 std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return failed || issued > k - kRingSlots; });
+                cv.wait(lk, [&] { return failed || issued > k - ring_slots; });
                 if (failed)
                     return;
                 lk.unlock();
-                if (hipEventSynchronize(sent[k % kRingSlots]) != hipSuccess) {
+                if (hipEventSynchronize(sent[k % ring_slots]) != hipSuccess) {
                     std::lock_guard<std::mutex> g(mu);
                     failed = true;
                     cv.notify_all();
                     return;
                 }
             }
-            uint8_t *slot = ring + (k % kRingSlots) * slice_bytes;
+            uint8_t *slot = ring + (k % ring_slots) * slice_bytes;
             for (size_t q = seg_begin[k]; q < seg_begin[k + 1]; ++q)
                 std::memcpy(slot + (segs[q].dst - k * slice_bytes), segs[q].src, segs[q].len);
             {
@@ -149,14 +151,14 @@ hipError_t transfer_staged(Slot &s, int hip_device, const std::vector<Piece> &pi
             const uint64_t lo = segs[seg_begin[k]].dst;
             const Segment &last = segs[seg_begin[k + 1] - 1];
             const uint64_t hi = last.dst + last.len;
-            e = hipMemcpyAsync(d_base + lo, ring + (k % kRingSlots) * slice_bytes + (lo - k * slice_bytes),
+            e = hipMemcpyAsync(d_base + lo, ring + (k % ring_slots) * slice_bytes + (lo - k * slice_bytes),
                                hi - lo, hipMemcpyHostToDevice, s.copy_stream);
         }
         if (e == hipSuccess && d_progress)
             e = hipMemcpyAsync(d_progress, &slice_numbers[k], sizeof(uint32_t),
                                hipMemcpyHostToDevice, s.copy_stream);
         if (e == hipSuccess)
-            e = hipEventRecord(sent[k % kRingSlots], s.copy_stream);
+            e = hipEventRecord(sent[k % ring_slots], s.copy_stream);
         {
             std::lock_guard<std::mutex> g(mu);
             if (e == hipSuccess)
@@ -176,7 +178,7 @@ hipError_t transfer_staged(Slot &s, int hip_device, const std::vector<Piece> &pi
         w.join();
     if (e == hipSuccess)
         e = hipStreamSynchronize(s.copy_stream);  // the ring must not be reused before it has left
-    for (unsigned r = 0; r < kRingSlots; ++r)
+    for (unsigned r = 0; r < ring_slots; ++r)
         (void)hipEventDestroy(sent[r]);
     return e;
 }
@@ -212,6 +214,12 @@ hipError_t transfer_to_device(Slot &s, int hip_device, const std::vector<Piece> 
     }
     if (end == 0)
         return hipSuccess;
+    if (d_progress == nullptr) {
+        // Nobody watches the slices: size them so that all staging threads get work
+        // even for a batch of a few tens of megabytes.
+        const uint64_t want = (end / (2 * kStageThreads) + 255) & ~uint64_t(255);
+        slice_bytes = std::min<uint64_t>(slice_bytes, std::max<uint64_t>(want, 1ull << 20));
+    }
     const uint64_t n_slices = (end + slice_bytes - 1) / slice_bytes;
     const char *env = std::getenv("SNAPPY_STAGE_PAGEABLE");  // "0": never stage (tuning)
     const bool may_stage = !(env && env[0] == '0');
