@@ -251,6 +251,10 @@ int hash_ranges_overlapped(SlotLease &lease, const HostRange *ranges, uint64_t f
     if ((st = s.d_tables.ensure(2 * table_bytes + n * sizeof(uint32_t))) != SNAPPY_OK) return st;
     if ((st = s.d_out.ensure(n * 20)) != SNAPPY_OK) return st;
     if ((st = s.h_stage.ensure(n_slices * sizeof(uint32_t))) != SNAPPY_OK) return st;
+    // Every allocation happens before the kernel is launched: freeing or allocating
+    // device or page-locked memory waits for running kernels, and this one will be
+    // waiting for the transfer.
+    if ((st = reserve_transfer_ring(s, slice_bytes, n_slices)) != SNAPPY_OK) return st;
     uint8_t *d_base = static_cast<uint8_t *>(s.d_data.ptr);
     uint64_t *d_off = static_cast<uint64_t *>(s.d_tables.ptr);
     uint64_t *d_len = d_off + n;
@@ -294,7 +298,9 @@ int hash_ranges_overlapped(SlotLease &lease, const HostRange *ranges, uint64_t f
     Sha1Arrival seen;
     SNAPPY_HIP_TRY(hipMemcpy(&seen, d_arrival, sizeof(seen), hipMemcpyDeviceToHost));
     if (seen.error) {
-        set_error_detail("SHA-1 kernel gave up waiting for its input");
+        set_error_detail("SHA-1 kernel gave up waiting for its input (" + std::to_string(seen.arrived) +
+                         " of " + std::to_string(n_slices) + " slices had arrived; a wave saw " + std::to_string(seen.reserved & 0xFFFFu) +
+                         " while waiting for " + std::to_string(seen.reserved >> 16) + ")");
         return SNAPPY_E_HIP;
     }
     finish_sha1_profile(lease);

@@ -48,10 +48,8 @@ __device__ __forceinline__ uint32_t rotate_in_group(uint32_t v)
         return __builtin_amdgcn_update_dpp(v, v, 0x13C, 0xF, 0xF, false);  // wave_ror:1
     else if constexpr (G == 16)
         return __builtin_amdgcn_update_dpp(v, v, 0x121, 0xF, 0xF, false);  // row_ror:1
-    else if constexpr (G == 4)
-        return __builtin_amdgcn_update_dpp(v, v, 0x93, 0xF, 0xF, false);   // quad_perm:[3,0,1,2]
     else
-        return v;
+        return __builtin_amdgcn_update_dpp(v, v, 0x93, 0xF, 0xF, false);   // quad_perm:[3,0,1,2]
 }
 
 // Waits until the transfer of the batch has passed slice `need` (per lane; 0 =
@@ -79,6 +77,9 @@ __device__ __forceinline__ bool wait_for_arrival(Sha1Arrival *arrival, uint32_t 
         idle_polls = (seen != last_seen) ? 0u : idle_polls + 1u;
         last_seen = seen;
         if (stop != 0 || idle_polls > kMaxArrivalPolls) {
+            if (stop == 0 && seen < need)  // what this wave was waiting for, for the error report
+                __hip_atomic_store(&arrival->reserved, (need << 16) | (seen & 0xFFFFu), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(&arrival->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             return false;
         }
@@ -99,10 +100,8 @@ __device__ __forceinline__ HopResult hop_once(const uint8_t *__restrict__ base,
                                               uint8_t *__restrict__ digests,
                                               Sha1Arrival *arrival, uint32_t lane)
 {
+    static_assert(G == 64 || G == 16 || G == 4, "group sizes with a DPP rotate");
     constexpr uint32_t kGroups = kWave / G;
-    // With one lane per message a superblock is a single block, too short to cover
-    // the latency of the next block's loads: prefetch two blocks ahead there.
-    constexpr bool kDeep = (G == 1);
     const uint32_t j = lane & (G - 1);  // position in the group
     const uint32_t grp = lane / G;
 
@@ -127,21 +126,14 @@ __device__ __forceinline__ HopResult hop_once(const uint8_t *__restrict__ base,
     for (int k = 0; k < 5; ++k)
         h[k] = kSha1Init[k];
 
-    // Raw dwords of this lane's block in the coming superblock(s), loaded ahead
-    // so the chain does not wait for memory.
-    uint32_t raw[17], raw_next[kDeep ? 17 : 1];
+    // Raw dwords of this lane's block in the coming superblock, loaded one
+    // superblock ahead so the chain does not wait for memory.
+    uint32_t raw[17];
 #pragma unroll
     for (int k = 0; k < 17; ++k)
         raw[k] = 0;
     if (j < n_full)
         load_block_raw(msg + (static_cast<uint64_t>(j) << 6), shift, raw);
-    if constexpr (kDeep) {
-#pragma unroll
-        for (int k = 0; k < 17; ++k)
-            raw_next[k] = 0;
-        if (j + G < n_full)
-            load_block_raw(msg + (static_cast<uint64_t>(j + G) << 6), shift, raw_next);
-    }
 
     for (uint64_t blk0 = 0;; blk0 += G) {
         const uint64_t left = blk0 < n_blocks ? n_blocks - blk0 : 0;
@@ -160,20 +152,7 @@ __device__ __forceinline__ HopResult hop_once(const uint8_t *__restrict__ base,
             else
                 make_length_block(len, w);
         }
-        if constexpr (G == 1) {
-            // One lane per message: nothing to share, so the schedule is expanded
-            // inside the rounds from a 16-word ring (613 instructions per block).
-#pragma unroll
-            for (int k = 0; k < 17; ++k)
-                raw[k] = raw_next[k];
-            if (blk0 + 2 < n_full)
-                load_block_raw(msg + ((blk0 + 2) << 6), shift, raw_next);
-            uint32_t moved[5] = {h[0], h[1], h[2], h[3], h[4]};
-            sha1_compress(moved, w);
-#pragma unroll
-            for (int k = 0; k < 5; ++k)
-                h[k] = nb ? moved[k] : h[k];
-        } else {
+        {
             // K is added to the schedule words here, off the chain.
             uint32_t wk[80];
 #pragma unroll
@@ -209,6 +188,78 @@ __device__ __forceinline__ HopResult hop_once(const uint8_t *__restrict__ base,
     }
     // After n_blocks hops the state sits in lane (n_blocks mod G) of the group.
     if (have && j == static_cast<uint32_t>(n_blocks & (G - 1)))
+        store_digest(digests + 20ull * task.out_index, h);
+    return kHopDone;
+}
+
+// One message per lane: claims the next 64 messages of tasks [first, end).  There
+// is nothing to share between lanes, so the schedule is expanded inside the
+// rounds from a 16-word ring (613 instructions per block and lane).  The loop
+// runs over full blocks only, two per iteration with the raw words of the two
+// after them already on their way; the padding blocks follow once for the whole
+// wave (the messages of a wave are of similar size, so little is lost to lanes
+// that wait for the longest).
+__device__ __forceinline__ void compress_if(bool on, uint32_t (&h)[5], uint32_t (&w)[16])
+{
+    uint32_t moved[5] = {h[0], h[1], h[2], h[3], h[4]};
+    sha1_compress(moved, w);
+#pragma unroll
+    for (int k = 0; k < 5; ++k)
+        h[k] = on ? moved[k] : h[k];
+}
+
+__device__ __forceinline__ HopResult lanes_once(const uint8_t *__restrict__ base,
+                                                const Sha1Task *__restrict__ tasks, uint32_t first,
+                                                uint32_t end, uint32_t *queue,
+                                                uint8_t *__restrict__ digests, Sha1Arrival *arrival,
+                                                uint32_t lane)
+{
+    const uint32_t i0 = first + wave_claim(queue, kWave, lane);
+    if (i0 >= end)
+        return kHopEmpty;
+    const bool have = i0 + lane < end;
+    const Sha1Task task = tasks[have ? i0 + lane : i0];
+    if (!wait_for_arrival(arrival, have ? task.ready_epoch : 0u))
+        return kHopGiveUp;
+    const uint8_t *msg = base + task.offset;
+    const uint64_t len = have ? task.len : 0;
+    const uint64_t n_full = len >> 6;
+    const uint32_t rem = static_cast<uint32_t>(len & 63u);
+    const uint32_t shift = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(msg) & 3u);
+
+    uint32_t h[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k)
+        h[k] = kSha1Init[k];
+    uint32_t even[17], odd[17];  // raw words of the next even-numbered and odd-numbered block
+#pragma unroll
+    for (int k = 0; k < 17; ++k)
+        even[k] = odd[k] = 0;
+    if (n_full > 0)
+        load_block_raw(msg, shift, even);
+    if (n_full > 1)
+        load_block_raw(msg + 64, shift, odd);
+
+    uint32_t w[16];
+    for (uint64_t blk = 0; __ballot(blk < n_full) != 0; blk += 2) {
+        raw_block_to_be(even, shift, w);
+        if (blk + 2 < n_full)
+            load_block_raw(msg + ((blk + 2) << 6), shift, even);
+        compress_if(blk < n_full, h, w);
+        if (__ballot(blk + 1 < n_full) == 0)
+            break;
+        raw_block_to_be(odd, shift, w);
+        if (blk + 3 < n_full)
+            load_block_raw(msg + ((blk + 3) << 6), shift, odd);
+        compress_if(blk + 1 < n_full, h, w);
+    }
+    const bool closed = load_tail_block_be(msg + (n_full << 6), rem, len, w);
+    compress_if(have, h, w);
+    if (__ballot(have && !closed) != 0) {
+        make_length_block(len, w);
+        compress_if(have && !closed, h, w);
+    }
+    if (have)
         store_digest(digests + 20ull * task.out_index, h);
     return kHopDone;
 }
@@ -265,7 +316,7 @@ sha1_hop_kernel(const uint8_t *__restrict__ base, const Sha1Task *__restrict__ t
         case 0: r = hop_once<64>(base, tasks, lo[0], hi[0], &state->queue[0].next, digests, arrival, lane); break;
         case 1: r = hop_once<16>(base, tasks, lo[1], hi[1], &state->queue[1].next, digests, arrival, lane); break;
         case 2: r = hop_once<4>(base, tasks, lo[2], hi[2], &state->queue[2].next, digests, arrival, lane); break;
-        default: r = hop_once<1>(base, tasks, lo[3], hi[3], &state->queue[3].next, digests, arrival, lane); break;
+        default: r = lanes_once(base, tasks, lo[3], hi[3], &state->queue[3].next, digests, arrival, lane); break;
         }
         if (r == kHopGiveUp)
             break;

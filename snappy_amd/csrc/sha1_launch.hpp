@@ -57,7 +57,7 @@ struct Sha1Arrival {
     uint32_t arrived;  // slices of the transfer that have landed
     uint32_t abort;    // host: the transfer failed, give up
     uint32_t error;    // kernel: gave up (abort seen, or no progress for ~10 s)
-    uint32_t reserved;
+    uint32_t reserved;  // kernel, on giving up: (slice waited for << 16) | slices seen
 };
 
 // Sorts the n messages by descending padded size into d_tasks and cuts the

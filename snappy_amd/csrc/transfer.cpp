@@ -13,6 +13,9 @@ namespace snappy {
 
 namespace {
 
+constexpr unsigned kRingSlots = 6;
+constexpr unsigned kStageThreads = 6;
+
 // Moves the pieces to the device in arena order on the slot's copy stream, cut at
 // slice boundaries, and raises the arrival counter after every complete slice.
 // Direct form: the sources are page-locked, every copy is a DMA from where the
@@ -55,9 +58,6 @@ hipError_t transfer_direct(Slot &s, const std::vector<Piece> &pieces, uint64_t s
 // calling thread sends each filled buffer on in slice order and raises the
 // counter behind it.  Several memcpy threads are what it takes to keep up with
 // the PCIe link.
-constexpr unsigned kRingSlots = 6;
-constexpr unsigned kStageThreads = 6;
-
 hipError_t transfer_staged(Slot &s, int hip_device, const std::vector<Piece> &pieces,
                            uint64_t slice_bytes, uint64_t n_slices, uint8_t *d_base,
                            uint32_t *d_progress, const uint32_t *slice_numbers)
@@ -84,7 +84,7 @@ hipError_t transfer_staged(Slot &s, int hip_device, const std::vector<Piece> &pi
 
     // No more ring than the batch has slices (a small batch must not pin 192 MiB).
     const unsigned ring_slots = static_cast<unsigned>(std::min<uint64_t>(kRingSlots, n_slices));
-    if (s.h_ring.ensure(static_cast<size_t>(ring_slots * slice_bytes)) != SNAPPY_OK)
+    if (reserve_transfer_ring(s, slice_bytes, n_slices) != SNAPPY_OK)
         return hipErrorOutOfMemory;
     uint8_t *ring = static_cast<uint8_t *>(s.h_ring.ptr);
     hipEvent_t sent[kRingSlots] = {};  // the first ring_slots are used
@@ -202,6 +202,11 @@ bool sources_are_page_locked(const std::vector<Piece> &pieces)
 }
 
 }  // namespace
+
+int reserve_transfer_ring(Slot &s, uint64_t slice_bytes, uint64_t n_slices)
+{
+    return s.h_ring.ensure(static_cast<size_t>(std::min<uint64_t>(kRingSlots, n_slices) * slice_bytes));
+}
 
 hipError_t transfer_to_device(Slot &s, int hip_device, const std::vector<Piece> &pieces,
                               uint64_t slice_bytes, uint8_t *d_base, uint32_t *d_progress,

@@ -30,4 +30,11 @@ hipError_t transfer_to_device(Slot &s, int hip_device, const std::vector<Piece> 
                               uint64_t slice_bytes, uint8_t *d_base, uint32_t *d_progress,
                               const uint32_t *slice_numbers);
 
+// Makes sure the slot's page-locked ring can carry a transfer of n_slices slices of
+// slice_bytes.  A caller that launches a kernel which waits for the transfer must
+// call this BEFORE the launch: growing the ring frees and allocates page-locked
+// memory, and those calls wait for every kernel on the device -- including the
+// one that is waiting for the transfer.
+int reserve_transfer_ring(Slot &s, uint64_t slice_bytes, uint64_t n_slices);
+
 }  // namespace snappy

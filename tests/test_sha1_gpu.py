@@ -297,3 +297,48 @@ def test_offsets_beyond_4_gib(snappy, oracle):
         force_path(path)
         got = snappy.sha1_batch_device(0, dev.data_ptr(), offsets, lengths)
         assert [g.tobytes() for g in got] == want, path
+
+
+def test_waiting_kernel_next_to_allocating_caller(snappy, oracle):
+    """One thread runs hash-while-copying batches (a kernel that waits for its transfer), another
+    thread keeps making calls whose growing sizes force the library to free and allocate device
+    and page-locked memory meanwhile.  Nobody may stall: the waiting kernel's own time limit would
+    turn a deadlock into an error here."""
+    import threading
+    import time
+
+    os.environ["SNAPPY_OVERLAP_MIN_BYTES"] = str(1 << 20)
+    os.environ["SNAPPY_OVERLAP_SLICE_BYTES"] = str(1 << 20)
+    rng = np.random.default_rng(91)
+    big = rng.integers(0, 256, size=48 << 20, dtype=np.uint8)
+    big_len = np.array([20 << 20, 9 << 20, 5 << 20, 1 << 20, 777], dtype=np.uint64)
+    big_off = np.concatenate([[0], np.cumsum(big_len)[:-1]]).astype(np.uint64)
+    big_want = oracle.sha1_batch_np(big, big_off, big_len)
+    errors = []
+
+    def overlapped():
+        try:
+            for _ in range(6):
+                if not np.array_equal(snappy.sha1_batch(big, big_off, big_len), big_want):
+                    errors.append("overlapped digests")
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    def growing():
+        try:
+            for k in range(12):
+                n = (3 + 5 * k) << 18          # below the overlap threshold at first, then above
+                blob = rng.integers(0, 256, size=n, dtype=np.uint8)
+                if snappy.sha1(blob.tobytes()) != oracle.sha1(blob.tobytes()):
+                    errors.append(("growing", k))
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    t0 = time.time()
+    threads = [threading.Thread(target=overlapped), threading.Thread(target=growing)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    assert time.time() - t0 < 9.0      # a stall would have lasted the kernel's 10 s limit
