@@ -553,7 +553,11 @@ def main():
         # that the host-pointer entry points (which use every visible device) stay on it.
         visible = os.environ.get("HIP_VISIBLE_DEVICES")
         ids = [v for v in visible.split(",") if v] if visible else None
-        os.environ["HIP_VISIBLE_DEVICES"] = ids[local_rank] if ids and local_rank < len(ids) else str(local_rank)
+        if os.environ.get("BENCH_REHEARSE_ON_ONE_GPU") == "1":
+            # Rehearsal of the N-rank flow on a one-GPU box: every rank shares GPU 0 (the numbers mean nothing).
+            os.environ["HIP_VISIBLE_DEVICES"] = ids[0] if ids else "0"
+        else:
+            os.environ["HIP_VISIBLE_DEVICES"] = ids[local_rank] if ids and local_rank < len(ids) else str(local_rank)
         local_rank = 0
 
     import torch
