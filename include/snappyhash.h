@@ -119,7 +119,7 @@ int snappy_sha1_batch_device(int device, const void *d_base, const uint64_t *off
 
 /* The same with everything resident: d_offsets, d_lengths (n entries each) and
  * d_digests (20*n bytes) are device memory too, so nothing but the launch
- * crosses PCIe; the size ordering and the split between kernels are computed on
+ * crosses PCIe; the size ordering and the cut into execution paths are computed on
  * the device.  Returns after the digests are in d_digests.  No counterpart in
  * the reference; for callers that keep asset tables on the GPU. */
 int snappy_sha1_batch_resident(int device, const void *d_base, const uint64_t *d_offsets,
