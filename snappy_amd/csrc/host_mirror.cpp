@@ -495,20 +495,41 @@ extern "C" int snappy_mcdf_import_to_dir(const char *mcdf_path, const char *work
     st = mcdf_slice_files(info.files, info.body_offset, payload_len, slices);
     if (st != SNAPPY_OK)
         return st;
+    // The map is filled in file order (last writer wins, McdfManager.cs:59-62); the file
+    // bodies go to disk from several threads, the first entry with a given hash writing it
+    // (the reference's File.Exists guard makes later ones no-ops).
     IgnoreCaseMap game_path_to_hash;
+    std::vector<std::string> hashes(slices.size());
+    std::map<std::string, size_t> first_with_hash;
+    std::vector<size_t> writers;
     for (size_t i = 0; i < slices.size(); ++i) {
         if (slices[i].status != SNAPPY_FILE_HASHED)
             continue;  // Length == 0, or a short read (logged and skipped by the reference)
         char h[41];
         hex40(digests.data() + 20 * i, h);
-        const std::string target = (files / (std::string(h) + ".dat")).string();
-        if (!fs::exists(target, ec) &&
-            !write_all_bytes(target, payload.data() + slices[i].offset, slices[i].length)) {
-            set_error_detail("cannot write " + target);
-            return SNAPPY_E_INVALID_ARG;
-        }
+        hashes[i] = h;
+        if (first_with_hash.emplace(hashes[i], i).second)
+            writers.push_back(i);
         for (const std::string &p : info.files[i].game_paths)
             game_path_to_hash.set(p, h);
+    }
+    std::atomic<bool> write_failed{false};
+    std::mutex fail_mu;
+    std::string failed_target;
+    parallel_for(writers.size(), [&](uint64_t w) {
+        const size_t i = writers[w];
+        const std::string target = (files / (hashes[i] + ".dat")).string();
+        std::error_code e2;
+        if (!fs::exists(target, e2) &&
+            !write_all_bytes(target, payload.data() + slices[i].offset, slices[i].length)) {
+            write_failed.store(true);
+            std::lock_guard<std::mutex> lk(fail_mu);
+            failed_target = target;
+        }
+    });
+    if (write_failed.load()) {
+        set_error_detail("cannot write " + failed_target);
+        return SNAPPY_E_INVALID_ARG;
     }
 
     // SaveSnapshotToDisk (SnapshotManager.cs:672-695).
