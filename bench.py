@@ -245,6 +245,7 @@ def run_mcdf(args, rank, world, local_rank, dist):
         ok = ok and (f["Length"] == 0 or digests[i].tobytes() == want)
         cur += f["Length"]
     del off
+    cpu = mcdf_cpu_baseline(streams, sizes) if not getattr(args, "no_cpu_baseline", False) else None
     k_lz4 = float(np.mean(lz4_ms))
     algo = comp_bytes + out_bytes
     achieved = algo / (k_lz4 * 1e-3) / GB
@@ -265,7 +266,45 @@ def run_mcdf(args, rank, world, local_rank, dist):
                      "kernel_ms": k_lz4, "algorithmic_bytes_per_launch": algo,
                      "sha1_kernel_ms": float(np.mean(sha_ms))},
         "digests_match_hashlib_sample": bool(ok),
+        **({"cpu_baseline": cpu} if cpu else {}),
     }
+
+
+def mcdf_cpu_baseline(streams, sizes):
+    """The import's CPU path on a bounded sample: lz4net decode (the oracle's scalar C decoder) and
+    SHA-1 of the decoded bytes (OpenSSL via hashlib, as one message: the hashing rate does not
+    depend on the slicing), one thread on the first archive, then one archive per thread."""
+    import hashlib
+    from concurrent.futures import ThreadPoolExecutor
+
+    from oracle import oracle
+
+    L = oracle.lib()
+
+    def one(a):
+        out = np.empty(sizes[a], dtype=np.uint8)
+        v = ctypes.c_uint64(0)
+        t0 = time.perf_counter()
+        st = L.oracle_lz4net_decode(streams[a].ctypes.data, streams[a].size, out.ctypes.data, out.size,
+                                    ctypes.byref(v))
+        t1 = time.perf_counter()
+        hashlib.sha1(out[: v.value]).digest()
+        t2 = time.perf_counter()
+        return st, v.value, t1 - t0, t2 - t1
+
+    st, n, t_dec, t_sha = one(0)
+    res = {"value": n / (t_dec + t_sha) / GB, "unit": "GB/s", "cores": 1, "kind": "port",
+           "sample": f"first archive ({n} decoded bytes): oracle/lz4_oracle.c decode + OpenSSL SHA-1, one thread",
+           "decode_only_value": n / t_dec / GB, "status": int(st)}
+    k = min(len(streams), max(1, min(16, os.cpu_count() or 1)))
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(k) as pool:
+        done = list(pool.map(one, range(k)))
+    dt = time.perf_counter() - t0
+    res["allcore_value"] = sum(d[1] for d in done) / dt / GB
+    res["allcore_threads"] = k
+    res.update(cpu_info())
+    return res
 
 
 def extra_workloads(args, lib, native, torch, device, local_rank):
@@ -318,7 +357,7 @@ def extra_workloads(args, lib, native, torch, device, local_rank):
     class A:
         pass
     a = A()
-    a.archives, a.archive_mib, a.steps, a.warmup = 8, 256.0, 2, 1
+    a.archives, a.archive_mib, a.steps, a.warmup, a.no_cpu_baseline = 8, 256.0, 2, 1, True
     m = run_mcdf(a, 0, 1, local_rank, None)
     res["mcdf_import"] = {"workload": m["config"]["workload"], "value": m["value"], "unit": "GB/s",
                           "ms_per_step": m["ms_per_step"], "roofline": m["roofline"],
