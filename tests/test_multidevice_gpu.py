@@ -54,3 +54,36 @@ def test_three_logical_devices(tmp_path):
                          timeout=300, env=env)
     assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
     assert "MULTIDEVICE OK" in out.stdout
+
+
+LIFECYCLE = r"""
+import sys
+import numpy as np
+sys.path.insert(0, {root!r})
+import snappy_amd as S
+L = S.native.lib()
+assert L.snappy_device_count() == 0            # nothing bound before the first call
+assert S.get_hash(b"abc") == "A9993E364706816ABA3E25717850C26C9CD0D89D"   # binds on first use
+assert L.snappy_device_count() >= 1
+big = np.random.default_rng(1).integers(0, 256, size=80 << 20, dtype=np.uint8)
+lens = np.array([50 << 20, 30 << 20], dtype=np.uint64)
+offs = np.array([0, 50 << 20], dtype=np.uint64)
+first = S.sha1_batch(big, offs, lens)            # hash-while-copying path, staging ring allocated
+L.snappy_shutdown()
+assert L.snappy_device_count() == 0
+again = S.sha1_batch(big, offs, lens)            # everything is rebuilt on demand
+assert np.array_equal(first, again)
+L.snappy_shutdown()
+assert L.snappy_init(1) == 0 and L.snappy_device_count() == 1
+assert S.get_hash(b"") == "DA39A3EE5E6B4B0D3255BFEF95601890AFD80709"
+L.snappy_shutdown()
+L.snappy_shutdown()                              # idempotent
+print("LIFECYCLE OK")
+"""
+
+
+def test_shutdown_and_reinit():
+    out = subprocess.run([sys.executable, "-c", LIFECYCLE.format(root=H.ROOT)], capture_output=True, text=True,
+                         timeout=300)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    assert "LIFECYCLE OK" in out.stdout
