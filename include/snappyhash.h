@@ -111,7 +111,8 @@ int snappy_digests_to_hex(const uint8_t *digests, uint64_t n, char *hex);
  * (0 <= device < snappy_device_count()).  d_base is a device pointer; offsets,
  * lengths and digests are host memory.  `stream` is a hipStream_t on that
  * device or NULL for a library stream; the call returns after the digests
- * have landed.  No counterpart in the reference (it hashes managed arrays);
+ * have landed.  Any byte offset works; files that start on 64-byte boundaries
+ * hash a few percent faster when there are many of them.  No counterpart in the reference (it hashes managed arrays);
  * it is the loop above for callers that keep assets resident on the GPU. */
 int snappy_sha1_batch_device(int device, const void *d_base, const uint64_t *offsets,
                              const uint64_t *lengths, uint64_t n, uint8_t *digests,

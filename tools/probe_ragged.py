@@ -1,6 +1,6 @@
 """Cost of ragged wave ends on the one-lane path: 10^6 files whose sizes are (a) uniform in
 4-32 KB, (b) the same total but quantised to one size per planning bucket (no ragged ends, same
-order and locality)."""
+order and locality), (c) the original sizes with every file starting on a 4/16/64/128-byte boundary."""
 import os
 import sys
 
@@ -9,9 +9,10 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def run(lib, native, torch, buf, lengths, label):
+def run(lib, native, torch, buf, lengths, label, align=1):
     n = len(lengths)
-    offsets = np.concatenate([[0], np.cumsum(lengths)[:-1]]).astype(np.int64)
+    padded = (lengths + align - 1) // align * align
+    offsets = np.concatenate([[0], np.cumsum(padded)[:-1]]).astype(np.int64)
     d_off = torch.from_numpy(offsets).cuda()
     d_len = torch.from_numpy(lengths.astype(np.int64)).cuda()
     d_dig = torch.zeros(n * 20, dtype=torch.uint8, device="cuda")
@@ -34,8 +35,10 @@ def main():
     lib.snappy_profile_enable(1)
     rng = np.random.default_rng(3)
     lengths = rng.integers(4096, 32769, size=1_000_000).astype(np.int64)
-    buf = torch.randint(0, 256, (int(lengths.sum()) + 4096,), dtype=torch.uint8, device="cuda")
+    buf = torch.randint(0, 256, (int(lengths.sum()) + 4096 + 128 * len(lengths),), dtype=torch.uint8, device="cuda")
     run(lib, native, torch, buf, lengths, "uniform sizes (ragged)")
+    for a in (4, 16, 64, 128):
+        run(lib, native, torch, buf, lengths, f"same, files aligned to {a} B", align=a)
     blocks = (lengths + 8) // 64 + 1
     e = np.floor(np.log2(blocks)).astype(np.int64)
     mant = (blocks >> (e - 3)) & 7
