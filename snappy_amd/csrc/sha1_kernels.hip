@@ -54,15 +54,17 @@ __device__ __forceinline__ uint32_t rotate_in_group(uint32_t v)
 
 // Waits until the transfer of the batch has passed slice `need` (per lane; 0 =
 // nothing to wait for).  Returns false when the wave should give up: the host
-// raised `abort`, another wave reported an error, or nothing arrived for ~10 s.
-// The words are in uncached memory; one coalesced load per poll, ~50 us apart.
-constexpr uint32_t kMaxArrivalPolls = 200000;
+// raised `abort`, another wave reported an error, or nothing arrived for
+// max_idle_polls polls (the host sets ~10 s).  The words are in uncached memory;
+// one coalesced load per poll, ~50 us apart.
 
 __device__ __forceinline__ bool wait_for_arrival(Sha1Arrival *arrival, uint32_t need)
 {
     if (arrival == nullptr || __ballot(need != 0) == 0)
         return true;
     uint32_t last_seen = 0, idle_polls = 0;
+    const uint32_t max_idle = __builtin_amdgcn_readfirstlane(
+        __hip_atomic_load(&arrival->max_idle_polls, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
     for (;;) {
         const uint32_t seen = __builtin_amdgcn_readfirstlane(
             __hip_atomic_load(&arrival->arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
@@ -76,7 +78,7 @@ __device__ __forceinline__ bool wait_for_arrival(Sha1Arrival *arrival, uint32_t 
             __hip_atomic_load(&arrival->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
         idle_polls = (seen != last_seen) ? 0u : idle_polls + 1u;
         last_seen = seen;
-        if (stop != 0 || idle_polls > kMaxArrivalPolls) {
+        if (stop != 0 || idle_polls > max_idle) {
             if (stop == 0 && seen < need)  // what this wave was waiting for, for the error report
                 __hip_atomic_store(&arrival->reserved, (need << 16) | (seen & 0xFFFFu), __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_SYSTEM);

@@ -58,6 +58,8 @@ struct Sha1Arrival {
     uint32_t abort;    // host: the transfer failed, give up
     uint32_t error;    // kernel: gave up (abort seen, or no progress for ~10 s)
     uint32_t reserved;  // kernel, on giving up: (slice waited for << 16) | slices seen
+    uint32_t max_idle_polls;  // host: polls (~50 us each) without progress before a wave gives up
+    uint32_t pad[3];
 };
 
 // Sorts the n messages by descending padded size into d_tasks and cuts the

@@ -24,7 +24,8 @@ def force_path(path):
 
 @pytest.fixture(autouse=True)
 def _clean_env():
-    keep = {k: os.environ.get(k) for k in (FORCE, "SNAPPY_OVERLAP_MIN_BYTES", "SNAPPY_OVERLAP_SLICE_BYTES")}
+    keep = {k: os.environ.get(k) for k in (FORCE, "SNAPPY_OVERLAP_MIN_BYTES", "SNAPPY_OVERLAP_SLICE_BYTES",
+                                           "SNAPPY_ARRIVAL_MAX_POLLS", "SNAPPY_TEST_TRANSFER_DELAY_MS")}
     yield
     for k, v in keep.items():
         if v is None:
@@ -342,3 +343,20 @@ def test_waiting_kernel_next_to_allocating_caller(snappy, oracle):
         t.join()
     assert not errors, errors
     assert time.time() - t0 < 9.0      # a stall would have lasted the kernel's 10 s limit
+
+
+def test_held_up_transfer_still_gives_right_digests(snappy, oracle):
+    """The kernel's patience is cut to a fraction of a second and the transfer is delayed beyond
+    it: the waves give up, and the call then hashes the data where it has arrived meanwhile."""
+    os.environ["SNAPPY_OVERLAP_MIN_BYTES"] = "0"
+    os.environ["SNAPPY_OVERLAP_SLICE_BYTES"] = "65536"
+    os.environ["SNAPPY_ARRIVAL_MAX_POLLS"] = "1000"
+    os.environ["SNAPPY_TEST_TRANSFER_DELAY_MS"] = "700"
+    rng = np.random.default_rng(95)
+    sizes = rng.integers(0, 300_000, size=40).astype(np.uint64)
+    offsets = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.uint64)
+    base = rng.integers(0, 256, size=int(sizes.sum()) + 1, dtype=np.uint8)
+    assert np.array_equal(snappy.sha1_batch(base, offsets, sizes), oracle.sha1_batch_np(base, offsets, sizes))
+    os.environ.pop("SNAPPY_TEST_TRANSFER_DELAY_MS")
+    os.environ.pop("SNAPPY_ARRIVAL_MAX_POLLS")
+    assert np.array_equal(snappy.sha1_batch(base, offsets, sizes), oracle.sha1_batch_np(base, offsets, sizes))
