@@ -9,6 +9,52 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
+def count_sequences(stream, max_chunks):
+    """Walks the lz4net framing and the LZ4 tokens of the first chunks."""
+    pos = seqs = decoded = 0
+
+    def varint():
+        nonlocal pos
+        v = shift = 0
+        while True:
+            b = int(stream[pos])
+            pos += 1
+            v |= (b & 0x7F) << shift
+            shift += 7
+            if b < 0x80:
+                return v
+
+    for _ in range(max_chunks):
+        if pos >= len(stream):
+            break
+        flags, n = varint(), varint()
+        c = varint() if flags & 1 else n
+        end = pos + c
+        decoded += n
+        if flags & 1:
+            while pos < end:
+                tok = int(stream[pos]); pos += 1
+                lit = tok >> 4
+                if lit == 15:
+                    while True:
+                        b = int(stream[pos]); pos += 1
+                        lit += b
+                        if b != 255:
+                            break
+                pos += lit
+                seqs += 1
+                if pos >= end:
+                    break
+                pos += 2
+                if tok & 15 == 15:
+                    while True:
+                        b = int(stream[pos]); pos += 1
+                        if b != 255:
+                            break
+        pos = end
+    return seqs, decoded
+
+
 def main():
     import bench
     from snappy_amd import native
@@ -37,7 +83,10 @@ def main():
         "asset-like mix": lambda: bench.asset_like_bytes(n, rng),
     }
     out = np.zeros(n + 4096, dtype=np.uint8)
+    only = os.environ.get("LZ4_KIND")          # substring filter, e.g. LZ4_KIND="x <6"
     for name, make in kinds.items():
+        if only and only not in name:
+            continue
         data = make()
         bound = ctypes.c_uint64(0)
         lib.snappy_lz4net_encode_bound(data.size, 0, ctypes.byref(bound))
@@ -53,6 +102,9 @@ def main():
                                                   ctypes.byref(v)), "decode")
             ms.append(lib.snappy_profile_last_ms(1))
         ok = v.value == n and np.array_equal(out[:n], data)
+        if only:   # sequences in the first chunks: token count by walking the blocks on the host
+            seqs, walked = count_sequences(stream[: w.value], 8)
+            print(f"   first chunks: {seqs} sequences in {walked} decoded bytes = {walked / max(seqs, 1):.1f} B per sequence")
         k = min(ms)
         print(f"{name:30s} ratio {n / w.value:8.2f}  decode {k:6.3f} ms  {(n + w.value) / k / 1e6:8.1f} GB/s (in+out)  "
               f"encode {enc_ms:7.2f} ms  roundtrip {'ok' if ok else 'WRONG'}", flush=True)
