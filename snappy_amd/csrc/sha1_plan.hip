@@ -95,7 +95,8 @@ plan_histogram(const uint64_t *__restrict__ lengths, uint32_t n, Sha1PlanState *
 // smallest bound is searched on a geometric grid.
 constexpr int kCoarseCandidates = 22;  // 11 octaves
 constexpr int kFineCandidates = 14;    // one octave around the coarse optimum
-constexpr int kPlanCandidates = kCoarseCandidates + (kSha1Paths - 1) + kFineCandidates;
+constexpr int kOwnCandidates = kSha1Paths;  // the largest file's own chain times
+constexpr int kPlanCandidates = kCoarseCandidates + kOwnCandidates + kFineCandidates;
 
 __device__ __forceinline__ int path_for(double edge_blocks, double d_max, const Sha1CostModel &m)
 {
@@ -151,14 +152,21 @@ plan_scan(Sha1PlanState *__restrict__ st, uint32_t n, Sha1CostModel m)
         // to the next faster path while everything else keeps the most room); then a
         // fine pass around the best so far.
         const double d_top = max_blocks * m.chain_ns[kSha1Paths - 1] * 1.0001;
-        for (int c = 0; c < kPlanCandidates; ++c) {
+        // With no more files than SIMDs every piece starts at once, the batch lasts as
+        // long as its largest file on the fastest path, and the cheapest plan is to
+        // let everything else take that long too: one candidate settles it.
+        const bool one_round = n <= m.n_simd;
+        for (int c = one_round ? kCoarseCandidates : 0;
+             c < (one_round ? kCoarseCandidates + 1 : kPlanCandidates); ++c) {
             double d_max;
             if (c < kCoarseCandidates)
                 d_max = d_top * exp2(-0.5 * static_cast<double>(c));
-            else if (c < kCoarseCandidates + kSha1Paths - 1)
-                d_max = max_blocks * m.chain_ns[c - kCoarseCandidates + 1] * 0.9999;
+            else if (c == kCoarseCandidates)
+                d_max = max_blocks * m.chain_ns[0] * 1.0001;
+            else if (c < kCoarseCandidates + kOwnCandidates)
+                d_max = max_blocks * m.chain_ns[c - kCoarseCandidates] * 0.9999;
             else
-                d_max = best_d * exp2((static_cast<double>(c - kCoarseCandidates - kSha1Paths + 1) -
+                d_max = best_d * exp2((static_cast<double>(c - kCoarseCandidates - kOwnCandidates) -
                                        0.5 * (kFineCandidates - 1)) / kFineCandidates);
             if (k < u_count) {
                 const int path = path_for(edge, d_max, m);
