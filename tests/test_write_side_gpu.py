@@ -127,3 +127,12 @@ def test_written_archive_imports(snappy, oracle, tmp_path):
     stored = {p.name for p in (tmp_path / "work").rglob("*.dat")}
     assert stored == {hashlib.sha1(b).hexdigest().upper() + ".dat" for b in bodies if b}
     assert snap
+
+
+@pytest.mark.parametrize("block", [1, 7, 12, 13, 64, 1000])
+def test_tiny_block_sizes(snappy, oracle, block):
+    data = H.compressible(5000, block) + b"\0" * 300 + H.random_bytes(77, block)
+    stream = snappy.lz4net_encode(data, block)
+    assert oracle.lz4net_decode(stream) == (0, data)
+    assert snappy.lz4net_decode(stream) == data
+    assert [n for _, n, _ in _chunks(stream)] == [min(block, len(data) - k) for k in range(0, len(data), block)]
