@@ -252,7 +252,7 @@ extern "C" int snappy_lz4net_decode(const uint8_t *in, uint64_t in_len, uint8_t 
     if (st != SNAPPY_OK)
         return st;
     if (dec.size)
-        SNAPPY_HIP_TRY(hipMemcpy(out, dec.d_payload, dec.size, hipMemcpyDeviceToHost));
+        SNAPPY_HIP_TRY(transfer_to_host(*lease.slot, lease.dev->hip_device, dec.d_payload, out, dec.size));
     *out_len = dec.size;
     return SNAPPY_OK;
 }

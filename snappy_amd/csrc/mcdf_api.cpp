@@ -9,6 +9,7 @@
 
 #include "lz4net_host.hpp"
 #include "mcdf_host.hpp"
+#include "transfer.hpp"
 #include "sha1_api.hpp"
 
 namespace snappy {
@@ -134,7 +135,8 @@ extern "C" int snappy_mcdf_decode_and_hash(const uint8_t *in, uint64_t in_len, u
         if (out_cap < size)
             return SNAPPY_E_CAPACITY;
         if (size)
-            SNAPPY_HIP_TRY(hipMemcpy(out_payload, jobs[0].d_payload, size, hipMemcpyDeviceToHost));
+            SNAPPY_HIP_TRY(transfer_to_host(*lease.slot, lease.dev->hip_device, jobs[0].d_payload,
+                                            out_payload, size));
     }
     return SNAPPY_OK;
 }

@@ -203,6 +203,123 @@ bool sources_are_page_locked(const std::vector<Piece> &pieces)
 
 }  // namespace
 
+hipError_t transfer_to_host(Slot &s, int hip_device, const uint8_t *d_src, uint8_t *dst,
+                            uint64_t bytes)
+{
+    if (bytes == 0)
+        return hipSuccess;
+    bool locked = false;
+    {
+        hipPointerAttribute_t attr;
+        if (hipPointerGetAttributes(&attr, dst) == hipSuccess)
+            locked = attr.type == hipMemoryTypeHost;
+        else
+            (void)hipGetLastError();
+    }
+    const char *env = std::getenv("SNAPPY_STAGE_PAGEABLE");
+    if (locked || bytes < (8ull << 20) || (env && env[0] == '0')) {
+        hipError_t e = hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, s.copy_stream);
+        return e == hipSuccess ? hipStreamSynchronize(s.copy_stream) : e;
+    }
+    const uint64_t want = (bytes / (2 * kStageThreads) + 255) & ~uint64_t(255);
+    const uint64_t slice = std::min<uint64_t>(kTransferSliceBytes, std::max<uint64_t>(want, 1ull << 20));
+    const uint64_t n_slices = (bytes + slice - 1) / slice;
+    const unsigned ring_slots = static_cast<unsigned>(std::min<uint64_t>(kRingSlots, n_slices));
+    if (reserve_transfer_ring(s, slice, n_slices) != SNAPPY_OK)
+        return hipErrorOutOfMemory;
+    uint8_t *ring = static_cast<uint8_t *>(s.h_ring.ptr);
+    hipEvent_t landed[kRingSlots] = {};  // the first ring_slots are used
+    for (unsigned r = 0; r < ring_slots; ++r)
+        if (hipEventCreateWithFlags(&landed[r], hipEventDisableTiming) != hipSuccess) {
+            for (unsigned q = 0; q < r; ++q)
+                (void)hipEventDestroy(landed[q]);
+            return hipErrorOutOfMemory;
+        }
+
+    std::mutex mu;
+    std::condition_variable cv;
+    uint64_t issued = 0;                     // slices whose copy into the ring has been enqueued
+    std::vector<char> drained(n_slices, 0);  // slices copied out of the ring
+    bool failed = false;
+    std::atomic<uint64_t> next_drain{0};
+
+    auto drain = [&] {
+        (void)hipSetDevice(hip_device);
+        for (;;) {
+            const uint64_t k = next_drain.fetch_add(1);
+            if (k >= n_slices)
+                return;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return failed || issued > k; });
+                if (failed)
+                    return;
+            }
+            if (hipEventSynchronize(landed[k % ring_slots]) != hipSuccess) {
+                std::lock_guard<std::mutex> g(mu);
+                failed = true;
+                cv.notify_all();
+                return;
+            }
+            const uint64_t len = std::min<uint64_t>(slice, bytes - k * slice);
+            std::memcpy(dst + k * slice, ring + (k % ring_slots) * slice, len);
+            {
+                std::lock_guard<std::mutex> g(mu);
+                drained[k] = 1;
+            }
+            cv.notify_all();
+        }
+    };
+    const unsigned n_threads = static_cast<unsigned>(std::min<uint64_t>(
+        n_slices, std::min<unsigned>(kStageThreads, std::max(1u, std::thread::hardware_concurrency()))));
+    std::vector<std::thread> workers;
+    for (unsigned t = 0; t < n_threads; ++t)
+        workers.emplace_back(drain);
+
+    hipError_t e = hipSuccess;
+    for (uint64_t k = 0; k < n_slices && e == hipSuccess; ++k) {
+        if (k >= ring_slots) {  // the ring slot must have been emptied
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return failed || drained[k - ring_slots]; });
+            if (failed) {
+                e = hipErrorUnknown;
+                break;
+            }
+        }
+        const uint64_t len = std::min<uint64_t>(slice, bytes - k * slice);
+        e = hipMemcpyAsync(ring + (k % ring_slots) * slice, d_src + k * slice, len, hipMemcpyDeviceToHost,
+                           s.copy_stream);
+        if (e == hipSuccess)
+            e = hipEventRecord(landed[k % ring_slots], s.copy_stream);
+        {
+            std::lock_guard<std::mutex> g(mu);
+            if (e == hipSuccess)
+                issued = k + 1;
+            else
+                failed = true;
+        }
+        cv.notify_all();
+    }
+    {
+        std::lock_guard<std::mutex> g(mu);
+        if (e != hipSuccess)
+            failed = true;
+    }
+    cv.notify_all();
+    for (auto &w : workers)
+        w.join();
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(s.copy_stream);
+    for (unsigned r = 0; r < ring_slots; ++r)
+        (void)hipEventDestroy(landed[r]);
+    {
+        std::lock_guard<std::mutex> g(mu);
+        if (e == hipSuccess && failed)
+            e = hipErrorUnknown;
+    }
+    return e;
+}
+
 int reserve_transfer_ring(Slot &s, uint64_t slice_bytes, uint64_t n_slices)
 {
     return s.h_ring.ensure(static_cast<size_t>(std::min<uint64_t>(kRingSlots, n_slices) * slice_bytes));

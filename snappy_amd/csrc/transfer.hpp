@@ -30,6 +30,13 @@ hipError_t transfer_to_device(Slot &s, int hip_device, const std::vector<Piece> 
                               uint64_t slice_bytes, uint8_t *d_base, uint32_t *d_progress,
                               const uint32_t *slice_numbers);
 
+// The other direction: bytes of device memory to a host buffer, after all work on
+// the slot's main stream has finished (the caller has synchronised it).  Ordinary
+// (pageable) destinations are served through the ring as well: the copy engine
+// fills ring buffers, several threads empty them into the caller's memory.
+hipError_t transfer_to_host(Slot &s, int hip_device, const uint8_t *d_src, uint8_t *dst,
+                            uint64_t bytes);
+
 // Makes sure the slot's page-locked ring can carry a transfer of n_slices slices of
 // slice_bytes.  A caller that launches a kernel which waits for the transfer must
 // call this BEFORE the launch: growing the ring frees and allocates page-locked
