@@ -24,6 +24,8 @@
 #include "lz4_launch.hpp"
 #include "wave_util.hpp"
 
+#include <cstdlib>
+
 namespace snappy {
 
 namespace {
@@ -34,33 +36,117 @@ constexpr uint32_t kLastLiterals = 5;
 
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 
-// 256-byte window of the chunk's compressed bytes: lane l holds the aligned
-// dword number (first_dword + l) counted from `aligned`.
+// All vector memory operations issued so far have completed (s_waitcnt vmcnt(0);
+// the other two counters are left at their maximum).
+__device__ __forceinline__ void wait_for_memory() { __builtin_amdgcn_s_waitcnt(0x0F70); }
+
+// The LDS counter alone: all LDS reads issued so far have returned.
+__device__ __forceinline__ void wait_for_lds() { __builtin_amdgcn_s_waitcnt(0xC07F); }
+
+// The chunk's compressed bytes on their way to the parser.  A memory round trip
+// takes as long as parsing some twenty tokens, so input is staged in LDS, up to
+// kStageBlocks blocks of 256 bytes per trip.  Tokens are parsed out of a
+// 256-byte window in registers, one dword per lane, which starts at any dword
+// and is moved on with one LDS read.
+constexpr uint32_t kStageBlocks = 32;  // 8 KiB per wave
+constexpr uint32_t kJumpBlocks = 4;    // staged after a jump (a long literal run was skipped)
+
 struct InputWindow {
     const uint32_t *aligned;  // dword-aligned pointer at or below the chunk's first byte
     uint32_t limit_dwords;    // dwords that may be read from `aligned`
-    uint32_t first_dword;     // uniform
-    uint32_t dword;           // per lane
+    uint32_t *stage;          // LDS, kStageBlocks * 64 dwords
+    uint32_t stage_block;     // uniform: number of the first staged block
+    uint32_t stage_count;     // uniform: blocks staged
+    uint32_t first;           // uniform: number of the dword held by lane 0
+    uint32_t a;               // per lane: dword first + lane
 
-    __device__ __forceinline__ void fill(uint32_t first, uint32_t lane)
+    // Every wait is placed here, on the paths that move the window.  A wait left
+    // to the compiler lands where the paths join again, is executed by every
+    // token, and waits for whatever stores are in flight by then as well (loads
+    // and stores share one in-order counter).
+    template <uint32_t kBlocks>
+    __device__ __forceinline__ void load_blocks(uint32_t blk, uint32_t slot, uint32_t lane)
     {
-        first_dword = first;
-        const uint32_t idx = first + lane;
-        dword = (idx < limit_dwords) ? aligned[idx] : 0u;
+        uint32_t w[kBlocks];
+#pragma unroll
+        for (uint32_t q = 0; q < kBlocks; ++q) {
+            const uint32_t idx = (blk + q) * 64u + lane;
+            w[q] = aligned[idx < limit_dwords ? idx : 0u];
+            w[q] = idx < limit_dwords ? w[q] : 0u;
+        }
+        wait_for_memory();
+#pragma unroll
+        for (uint32_t q = 0; q < kBlocks; ++q)
+            stage[(slot + q) * 64u + lane] = w[q];
+    }
+
+    // Stages the blocks from `blk` on: all of them when the parser ran off the end
+    // of what was staged (tokens are dense here), a few after a jump.
+    __device__ __forceinline__ void restage(uint32_t blk, bool all, uint32_t lane)
+    {
+        load_blocks<kJumpBlocks>(blk, 0, lane);
+        stage_count = kJumpBlocks;
+        if (all) {
+            load_blocks<(kStageBlocks - kJumpBlocks) / 2u>(blk + kJumpBlocks, kJumpBlocks, lane);
+            load_blocks<(kStageBlocks - kJumpBlocks) / 2u>(blk + (kStageBlocks + kJumpBlocks) / 2u,
+                                                           (kStageBlocks + kJumpBlocks) / 2u, lane);
+            stage_count = kStageBlocks;
+        }
+        stage_block = blk;
+    }
+
+    // Position one past the staged bytes.
+    __device__ __forceinline__ uint32_t stage_end() const { return (stage_block + stage_count) * 256u; }
+
+    // Moves the window so that it starts with the dword of byte position `pos`.
+    __device__ __forceinline__ void slide(uint32_t pos, uint32_t lane)
+    {
+        const uint32_t dw = pos >> 2;
+        uint32_t at = dw - stage_block * 64u;  // huge when dw lies before the stage
+        if (at + 64u > stage_count * 64u) {
+            // Running off the end of a full stage means dense tokens; anything else is a jump.
+            const bool dense = stage_count == kStageBlocks && at < (kStageBlocks + 1u) * 64u;
+            restage(pos >> 8, dense, lane);
+            at = dw - stage_block * 64u;
+        }
+        a = stage[at + lane];
+        first = dw;
+        wait_for_lds();
+    }
+
+    __device__ __forceinline__ void reset(uint32_t lane)
+    {
+        restage(0, false, lane);
+        slide(0, lane);
     }
 
     // The four bytes at byte position `pos` (counted from `aligned`), little-endian.
     __device__ __forceinline__ uint32_t peek32(uint32_t pos, uint32_t lane)
     {
-        uint32_t di = (pos >> 2) - first_dword;
+        uint32_t di = (pos >> 2) - first;
         if (di >= 63u) {  // also catches positions before the window
-            fill(pos >> 2, lane);
+            slide(pos, lane);
             di = 0;
         }
-        const uint32_t lo = __builtin_amdgcn_readlane(dword, di);
-        const uint32_t hi = __builtin_amdgcn_readlane(dword, di + 1u);
+        const uint32_t lo = __builtin_amdgcn_readlane(a, di);
+        const uint32_t hi = __builtin_amdgcn_readlane(a, di + 1u);
         const uint64_t both = (static_cast<uint64_t>(hi) << 32) | lo;
         return static_cast<uint32_t>(both >> ((pos & 3u) * 8u));
+    }
+
+    // Makes the window hold the n bytes from `pos` on (n <= 252).
+    __device__ __forceinline__ void cover(uint32_t pos, uint32_t n, uint32_t lane)
+    {
+        if ((pos >> 2) < first || ((pos + n + 3u) >> 2) > first + 64u)
+            slide(pos, lane);
+    }
+
+    // Four staged bytes at `pos`, which any lane may ask for; [pos, pos + 4) is staged.
+    __device__ __forceinline__ uint32_t staged32(uint32_t pos) const
+    {
+        uint32_t w;
+        __builtin_memcpy(&w, reinterpret_cast<const uint8_t *>(stage) + (pos - stage_block * 256u), 4);
+        return w;
     }
 };
 
@@ -240,6 +326,38 @@ constexpr uint32_t kHist = 8192;       // bytes of recent output per wave in LDS
 constexpr uint32_t kShortLit = 192;    // longest literal run served from the window registers
 constexpr uint32_t kShortMatch = 512;  // longest match served from the ring
 
+__device__ __forceinline__ uint32_t load32(const uint8_t *p)
+{
+    uint32_t w;
+    __builtin_memcpy(&w, p, 4);  // a dword access at any byte address
+    return w;
+}
+
+__device__ __forceinline__ void store32(uint8_t *p, uint32_t w) { __builtin_memcpy(p, &w, 4); }
+
+// Four ring bytes from output position `pos` on, and the same as a write.
+__device__ __forceinline__ uint32_t ring_read32(const uint8_t *ring, uint32_t pos)
+{
+    const uint32_t i = pos & (kHist - 1u);
+    if (i <= kHist - 4u)
+        return load32(ring + i);
+    uint32_t w = 0;
+    for (uint32_t q = 0; q < 4u; ++q)
+        w |= static_cast<uint32_t>(ring[(i + q) & (kHist - 1u)]) << (8u * q);
+    return w;
+}
+
+__device__ __forceinline__ void ring_write32(uint8_t *ring, uint32_t pos, uint32_t w)
+{
+    const uint32_t i = pos & (kHist - 1u);
+    if (i <= kHist - 4u) {
+        store32(ring + i, w);
+    } else {
+        for (uint32_t q = 0; q < 4u; ++q)
+            ring[(i + q) & (kHist - 1u)] = static_cast<uint8_t>(w >> (8u * q));
+    }
+}
+
 __device__ __forceinline__ void emit_short_literals(const InputWindow &win, uint32_t ip,
                                                     uint32_t lit, uint8_t *out, uint8_t *ring,
                                                     uint32_t op, uint32_t lane)
@@ -249,9 +367,9 @@ __device__ __forceinline__ void emit_short_literals(const InputWindow &win, uint
         const uint32_t i = base + lane;
         const bool on = i < lit;
         const uint32_t pos = ip + (on ? i : 0u);
-        const uint32_t from_lane = (pos >> 2) - win.first_dword;
+        const uint32_t from_lane = (pos >> 2) - win.first;
         const uint32_t word = static_cast<uint32_t>(
-            __builtin_amdgcn_ds_bpermute(static_cast<int>(from_lane << 2), static_cast<int>(win.dword)));
+            __builtin_amdgcn_ds_bpermute(static_cast<int>(from_lane << 2), static_cast<int>(win.a)));
         const uint8_t byte = static_cast<uint8_t>(word >> ((pos & 3u) * 8u));
         if (on) {
             out[op + i] = byte;
@@ -286,9 +404,230 @@ __device__ __forceinline__ void emit_short_match(uint8_t *out, uint8_t *ring, ui
     }
 }
 
+// Runs of plain short sequences are taken up to 64 at a time.  The only serial
+// part is finding where each token starts, which takes the token and the byte
+// behind it and touches no memory.  Lane j then reads sequence j's lengths and
+// offset out of the staged input, a prefix sum gives every sequence its place in
+// the output, and the batch is cut in front of the first sequence it must not
+// take.  Every lane copies its own sequence's literals from the stage.  The
+// matches follow in rounds: a match is copied once everything it reads is
+// final, that is, once its source ends at or before the output of the first
+// match still waiting.  Sources in reach of the ring are read from LDS; sources
+// that end before the batch's output begins are read from memory.
+//
+// A sequence is taken only if the one-at-a-time code below would accept it with
+// room to spare, so every rule about the end of a block stays with that code:
+// at most one length-extension byte each, a match that does not overlap its own
+// output within one copy step, 4 more input bytes and 16 more output bytes
+// behind it, and a source that is either in the ring or entirely older than the
+// batch.
+constexpr uint32_t kBatchLit = 240;
+// Measurement builds (-DSNAPPY_LZ4_PHASE_SWITCHES) can leave out one kind of copy
+// (tuning bits 1-3; the output is then wrong) to see what each costs.
+#ifdef SNAPPY_LZ4_PHASE_SWITCHES
+constexpr uint32_t kPhaseSwitches = 0xEu;
+#else
+constexpr uint32_t kPhaseSwitches = 0u;
+#endif
+constexpr uint32_t kBatchMatch = 255;
+constexpr uint32_t kBatchSpan = 4096;   // most output one batch produces
+constexpr uint32_t kBatchInput = 512;   // staged bytes a sequence may touch from its token on
+constexpr uint32_t kLitStep = 8;        // dwords a lane has in flight per step when copying literals
+constexpr uint32_t kMatchStep = 4;      // and matches: a match may repeat a pattern of 16 bytes or more
+
+// The first `count` (at most 4 count) bytes of `w` go to output position `pos`
+// and to the ring.
+__device__ __forceinline__ void put_exact(uint8_t *dst, uint8_t *ring, uint32_t pos, uint32_t w,
+                                          uint32_t count)
+{
+    if (count >= 4u) {
+        store32(dst + pos, w);
+        ring_write32(ring, pos, w);
+    } else {
+        for (uint32_t q = 0; q < count; ++q) {
+            const uint8_t byte = static_cast<uint8_t>(w >> (8u * q));
+            dst[pos + q] = byte;
+            ring[(pos + q) & (kHist - 1u)] = byte;
+        }
+    }
+}
+
+// Sum over the lanes up to and including this one.
+__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v)
+{
+    // Within rows of 16 lanes: shifts by 1, 2, 4, 8 (lanes shifted in from outside the row add 0).
+    v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x111, 0xF, 0xF, true));
+    v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x112, 0xF, 0xF, true));
+    v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x114, 0xF, 0xF, true));
+    v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x118, 0xF, 0xF, true));
+    // Lane 15 of a row into the next row (rows 1 and 3), then lane 31 into rows 2 and 3.
+    v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x142, 0xA, 0xF, false));
+    v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x143, 0xC, 0xF, false));
+    return v;
+}
+
+// Returns the number of sequences taken.  `walk` is how many tokens the next call
+// should look at: a stream of sequences that are not for this code should not pay
+// for 64 tokens walked in vain each time.
+__device__ __forceinline__ uint32_t take_batch(InputWindow &win, uint8_t *dst, uint8_t *ring,
+                                               uint32_t &ip_io, uint32_t &op_io, uint32_t valid_from,
+                                               uint32_t iend, uint32_t oend, uint32_t &walk,
+                                               uint32_t lane, uint32_t tuning)
+{
+    uint32_t ip = ip_io;  // uniform
+    const uint32_t start = op_io;
+    const bool likely = walk >= 16u;  // recent batches were worth their while
+    if (ip < win.stage_block * 256u || ip + (likely ? 8u : 1u) * kBatchInput > win.stage_end()) {
+        // Not enough staged for a batch.  Staging more pays when batches have been
+        // taken lately; otherwise the one-at-a-time code stages what it needs.
+        if (!likely || ip + kBatchInput > iend)
+            return 0;
+        win.restage(ip >> 8, true, lane);
+        win.slide(ip, lane);
+    }
+    const uint32_t stage_end = win.stage_end();
+
+    // Where the tokens start.
+    uint32_t n = 0;
+    uint32_t my_ip = 0;  // lane j: sequence j
+    while (n < walk && ip + kBatchInput <= stage_end) {
+        const uint32_t r = uni(win.peek32(ip, lane));
+        const uint32_t lit = (r >> 4) & 15u;
+        uint32_t len = 3u + lit;
+        if (lit == 15u) {
+            const uint32_t more = (r >> 8) & 255u;
+            if (more > kBatchLit - 15u)
+                break;
+            len += 1u + more;
+        }
+        if ((r & 15u) == 15u) {
+            const uint32_t more = uni(win.peek32(ip + len, lane)) & 255u;
+            if (more > kBatchMatch - 19u)
+                break;
+            len += 1u;
+        }
+        my_ip = (lane == n) ? ip : my_ip;
+        ++n;
+        ip += len;
+    }
+    if (n == 0) {
+        walk = 4;
+        return 0;
+    }
+
+    // What each sequence is.
+    const bool walked = lane < n;
+    const uint32_t at = walked ? my_ip : ip_io;
+    const uint32_t r1 = win.staged32(at);
+    uint32_t lit = (r1 >> 4) & 15u;
+    uint32_t ml = r1 & 15u;
+    uint32_t lip = at + 1u;
+    if (lit == 15u) {
+        lit += (r1 >> 8) & 255u;
+        lip += 1u;
+    }
+    uint32_t after = lip + lit;  // the offset; then the next token
+    const uint32_t r2 = win.staged32(after);
+    const uint32_t off = r2 & 0xFFFFu;
+    after += 2u;
+    if (ml == 15u) {
+        ml += (r2 >> 16) & 255u;
+        after += 1u;
+    }
+    ml += 4u;
+    const uint32_t out_len = walked ? lit + ml : 0u;
+    const uint32_t out_end = start + wave_inclusive_sum(out_len);
+    const uint32_t my_op = out_end - out_len;
+    const uint32_t mo = my_op + lit;
+    const uint32_t s = mo - off;
+    const bool in_ring = s >= valid_from && s + kHist >= start + kBatchSpan;
+    const bool bad = !walked || lit > kBatchLit || ml > kBatchMatch || (off < ml && off < 4u * kMatchStep) ||
+                     off > mo || off == 0u || after + 4u > iend || out_end + 16u > oend ||
+                     out_end - start > kBatchSpan || (!in_ring && s + ml > start) ||
+                     (off < ml && !in_ring);
+    const uint64_t stop = __builtin_amdgcn_ballot_w64(bad);
+    const uint32_t take = stop ? static_cast<uint32_t>(__builtin_ctzll(stop)) : kWave;
+    walk = take >= walk ? (2u * walk < kWave ? 2u * walk : kWave) : (take + 4u < kWave ? take + 4u : kWave);
+    if (take == 0)
+        return 0;
+    ip_io = take < n ? __builtin_amdgcn_readlane(my_ip, take) : ip;
+    op_io = __builtin_amdgcn_readlane(out_end, take - 1u);
+
+    const bool mine = lane < take;
+    const uint32_t my_lit = mine ? lit : 0u;
+    const uint32_t my_ml = mine ? ml : 0u;
+
+    // Literals, whole dwords: up to 3 bytes too many land where the sequence's own
+    // match (4 bytes at least) is written afterwards.
+    if (!(tuning & kPhaseSwitches & 2u)) {
+        for (uint32_t t = 0; __builtin_amdgcn_ballot_w64(t < my_lit) != 0; t += 4u * kLitStep) {
+            uint32_t w[kLitStep];
+#pragma unroll
+            for (uint32_t k = 0; k < kLitStep; ++k)
+                if (t + 4u * k < my_lit)
+                    w[k] = win.staged32(lip + t + 4u * k);
+#pragma unroll
+            for (uint32_t k = 0; k < kLitStep; ++k)
+                if (t + 4u * k < my_lit) {
+                    store32(dst + my_op + t + 4u * k, w[k]);
+                    ring_write32(ring, my_op + t + 4u * k, w[k]);
+                }
+        }
+    }
+
+    // Matches are written to the byte: what follows a match is already in place.
+    // First those whose source is older than the batch and out of the ring's reach.
+    // Every lane loads, from a harmless address when it has nothing to copy, so
+    // that one wait covers the loads of a step and the stores behind it need none.
+    bool waiting = mine;
+    if (!(tuning & kPhaseSwitches & 4u) && __builtin_amdgcn_ballot_w64(mine && !in_ring) != 0) {
+        const bool far = mine && !in_ring;
+        const uint32_t len = far ? ml : 0u;
+        const uint8_t *from = dst + (far ? s : 0u);
+        for (uint32_t t = 0; __builtin_amdgcn_ballot_w64(t < len) != 0; t += 4u * kLitStep) {
+            uint32_t w[kLitStep];
+#pragma unroll
+            for (uint32_t k = 0; k < kLitStep; ++k)
+                w[k] = load32(from + ((t + 4u * k < len) ? t + 4u * k : 0u));
+            wait_for_memory();
+#pragma unroll
+            for (uint32_t k = 0; k < kLitStep; ++k)
+                put_exact(dst, ring, mo + t + 4u * k, w[k], len > t + 4u * k ? len - (t + 4u * k) : 0u);
+        }
+        waiting = waiting && !far;
+    }
+
+    // Then, in rounds, those that read the ring.  A match that repeats a pattern
+    // (offset < length) needs the pattern only; each step reads what the steps
+    // before it wrote, LDS operations of one wave taking effect in order.
+    const uint32_t need = off < my_ml ? off : my_ml;
+    for (;;) {
+        const uint64_t left = __builtin_amdgcn_ballot_w64(waiting);
+        if (left == 0 || (tuning & kPhaseSwitches & 8u))
+            break;
+        const uint32_t front = __builtin_amdgcn_readlane(mo, static_cast<uint32_t>(__builtin_ctzll(left)));
+        // (A source inside the sequence's own literals is final from the start.)
+        const bool go = waiting && (s + need <= front || s >= my_op);
+        const uint32_t len = go ? my_ml : 0u;
+        for (uint32_t t = 0; __builtin_amdgcn_ballot_w64(t < len) != 0; t += 4u * kMatchStep) {
+            uint32_t w[kMatchStep];
+#pragma unroll
+            for (uint32_t k = 0; k < kMatchStep; ++k)
+                if (t + 4u * k < len)
+                    w[k] = ring_read32(ring, s + t + 4u * k);
+#pragma unroll
+            for (uint32_t k = 0; k < kMatchStep; ++k)
+                put_exact(dst, ring, mo + t + 4u * k, w[k], len > t + 4u * k ? len - (t + 4u * k) : 0u);
+        }
+        waiting = waiting && !go;
+    }
+    return take;
+}
+
 // Decodes one compressed chunk; returns true when the block is well-formed.
 __device__ bool decode_block(const uint8_t *__restrict__ in_base, uint64_t in_alloc,
-                             const Lz4Chunk &ck, uint8_t *out_base, uint8_t *ring, uint32_t lane)
+                             const Lz4Chunk &ck, uint8_t *out_base, uint8_t *ring, uint32_t *stage,
+                             uint32_t lane, uint32_t tuning)
 {
     const uint8_t *src = in_base + ck.in_off;
     uint8_t *dst = out_base + ck.out_off;
@@ -300,14 +639,18 @@ __device__ bool decode_block(const uint8_t *__restrict__ in_base, uint64_t in_al
     win.aligned = reinterpret_cast<const uint32_t *>(src - in_shift);
     const uint64_t avail = in_alloc - (ck.in_off - in_shift);
     win.limit_dwords = static_cast<uint32_t>(avail >> 2 > 0xFFFFFFFFull ? 0xFFFFFFFFull : avail >> 2);
-    win.fill(0, lane);
+    win.stage = stage;
+    win.reset(lane);
 
     uint32_t ip = in_shift;  // uniform
     uint32_t op = 0;         // uniform
     uint32_t valid_from = 0; // uniform: the ring holds output positions [valid_from, op)
+    uint32_t walk = kWave;   // uniform: tokens the next batch looks at
     const uint8_t *src_al = src - in_shift;
 
     for (;;) {
+        if (!(tuning & 1u) && take_batch(win, dst, ring, ip, op, valid_from, iend, oend, walk, lane, tuning) >= 16u)
+            continue;  // more of the same is likely
         if (ip >= iend)
             return false;
         uint32_t bytes = uni(win.peek32(ip, lane));
@@ -345,8 +688,7 @@ __device__ bool decode_block(const uint8_t *__restrict__ in_base, uint64_t in_al
         if (last && op + lit != oend)
             return false;
         if (lit != 0u && lit <= kShortLit) {
-            if ((ip >> 2) < win.first_dword || ((ip + lit + 3u) >> 2) > win.first_dword + 64u)
-                win.fill(ip >> 2, lane);
+            win.cover(ip, lit, lane);
             emit_short_literals(win, ip, lit, dst, ring, op, lane);
         } else if (lit != 0u) {
             copy_run(dst + op, src_al + ip, lit, lane);
@@ -414,11 +756,13 @@ __device__ bool decode_block(const uint8_t *__restrict__ in_base, uint64_t in_al
 __global__ void __launch_bounds__(256)
 lz4_decode_kernel(const uint8_t *__restrict__ in_base, uint64_t in_alloc, uint8_t *out_base,
                   const Lz4Chunk *__restrict__ chunks, uint32_t n_chunks,
-                  uint32_t *__restrict__ queue, uint32_t *__restrict__ status)
+                  uint32_t *__restrict__ queue, uint32_t *__restrict__ status, uint32_t tuning)
 {
-    __shared__ uint8_t rings[4][kHist];
+    __shared__ __attribute__((aligned(16))) uint8_t rings[4][kHist];
     const uint32_t lane = threadIdx.x & (kWave - 1);
+    __shared__ uint32_t stages[4][kStageBlocks * 64u];
     uint8_t *ring = rings[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)];
+    uint32_t *stage = stages[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)];
     for (;;) {
         const uint32_t i = wave_claim(queue, 1u, lane);
         if (i >= n_chunks)
@@ -426,7 +770,7 @@ lz4_decode_kernel(const uint8_t *__restrict__ in_base, uint64_t in_alloc, uint8_
         const Lz4Chunk ck = chunks[i];
         bool ok = true;
         if (ck.compressed) {
-            ok = decode_block(in_base, in_alloc, ck, out_base, ring, lane);
+            ok = decode_block(in_base, in_alloc, ck, out_base, ring, stage, lane, tuning);
         } else {
             copy_run(out_base + ck.out_off, in_base + ck.in_off, ck.orig_len, lane);
         }
@@ -443,8 +787,13 @@ hipError_t launch_lz4_decode(const uint8_t *d_in, uint64_t in_alloc, uint8_t *d_
 {
     if (n_chunks == 0 || blocks <= 0)
         return hipSuccess;
+    // SNAPPY_LZ4_TUNING, bit 0: every sequence takes the one-at-a-time path (for comparisons).
+    static const uint32_t tuning = [] {
+        const char *env = std::getenv("SNAPPY_LZ4_TUNING");
+        return env ? static_cast<uint32_t>(std::strtoul(env, nullptr, 0)) : 0u;
+    }();
     hipLaunchKernelGGL(lz4_decode_kernel, dim3(blocks), dim3(256), 0, stream, d_in, in_alloc, d_out,
-                       d_chunks, n_chunks, d_queue, d_status);
+                       d_chunks, n_chunks, d_queue, d_status, tuning);
     return hipGetLastError();
 }
 

@@ -55,6 +55,99 @@ def count_sequences(stream, max_chunks):
     return seqs, decoded
 
 
+def batch_census(stream, max_chunks):
+    """Which sequences of the first chunks would the decoder take in batches, and what ends a batch."""
+    from collections import Counter
+    pos = 0
+    why = Counter()
+    sizes = []
+
+    def varint():
+        nonlocal pos
+        v = shift = 0
+        while True:
+            b = int(stream[pos]); pos += 1
+            v |= (b & 0x7F) << shift
+            shift += 7
+            if b < 0x80:
+                return v
+
+    for _ in range(max_chunks):
+        if pos >= len(stream):
+            break
+        flags, n = varint(), varint()
+        c = varint() if flags & 1 else n
+        end = pos + c
+        if flags & 1:
+            op = 0
+            start, count = 0, 0
+
+            def close(reason):
+                nonlocal start, count
+                why[reason] += 1
+                if count:
+                    sizes.append(count)
+                count = 0
+
+            while pos < end:
+                tok = int(stream[pos]); pos += 1
+                lit, ext_l = tok >> 4, 0
+                if lit == 15:
+                    while True:
+                        b = int(stream[pos]); pos += 1; ext_l += 1
+                        lit += b
+                        if b != 255:
+                            break
+                pos += lit
+                if pos >= end:
+                    close("end of block")
+                    break
+                off = int(stream[pos]) | int(stream[pos + 1]) << 8
+                pos += 2
+                ml, ext_m = tok & 15, 0
+                if ml == 15:
+                    while True:
+                        b = int(stream[pos]); pos += 1; ext_m += 1
+                        ml += b
+                        if b != 255:
+                            break
+                ml += 4
+                if count == 0:
+                    start = op
+                mo = op + lit
+                reason = None
+                if lit > 240 or ext_l > 1:
+                    reason = "long literals"
+                elif ml > 255 or ext_m > 1:
+                    reason = "long match"
+                elif off < ml:
+                    reason = "overlapping match"
+                elif pos + 4 > end or mo + ml + 16 > n:
+                    reason = "near the end"
+                elif mo + ml - start > 4096:
+                    reason = "span"
+                if reason is None:
+                    s = mo - off
+                    in_ring = s + 8192 >= start + 4096
+                    if not in_ring and s + ml > start:
+                        reason = "source straddles"
+                if reason == "span":
+                    close("full (span)")
+                    start = op
+                    count = 1
+                elif reason:
+                    close(reason)
+                else:
+                    count += 1
+                    if count == 64:
+                        close("full (64)")
+                op = mo + ml
+        pos = end
+    total = sum(sizes)
+    print(f"   batches: {len(sizes)}, sequences in batches {total}, mean size {total / max(len(sizes), 1):.1f}; "
+          f"what ended them: {dict(why)}")
+
+
 def main():
     import bench
     from snappy_amd import native
@@ -66,15 +159,33 @@ def main():
     n = 2 << 30
 
     def motif(lo, hi, reps_hi):
+        unit = 64 << 20   # generated once, then repeated: chunks are compressed independently
         parts, total = [], 0
-        while total < n:
+        while total < unit:
             m = rng.integers(0, 256, size=int(rng.integers(lo, hi)), dtype=np.uint8)
             seg = np.tile(m, int(rng.integers(2, reps_hi)))
             parts.append(seg)
             total += seg.size
-        return np.concatenate(parts)[:n]
+        return np.tile(np.concatenate(parts)[:unit], n // unit)
+
+    def lz_like(max_lit, max_match, max_off):
+        """Short literal runs and short copies of earlier bytes, as a compressor finds them in
+        textures and meshes; 16 different 1 MiB chunks, repeated."""
+        chunks = []
+        for _ in range(16):
+            buf = bytearray(rng.integers(0, 256, size=64, dtype=np.uint8).tobytes())
+            while len(buf) < (1 << 20):
+                buf += rng.integers(0, 256, size=int(rng.integers(0, max_lit + 1)), dtype=np.uint8).tobytes()
+                ml = int(rng.integers(4, min(max_match, len(buf)) + 1))
+                off = int(rng.integers(ml, min(len(buf), max_off) + 1))
+                buf += buf[len(buf) - off: len(buf) - off + ml]
+            chunks.append(np.frombuffer(bytes(buf[: 1 << 20]), dtype=np.uint8))
+        return np.tile(np.concatenate(chunks), n // (16 << 20))
 
     kinds = {
+        "lz-like lit<=24 match<=36": lambda: lz_like(24, 36, 65535),
+        "lz-like lit<=8 match<=20 near": lambda: lz_like(8, 20, 2048),
+        "lz-like lit<=100 match<=200": lambda: lz_like(100, 200, 65535),
         "random (stored chunks)": lambda: rng.integers(0, 256, size=n, dtype=np.uint8),
         "zeros (one match per chunk)": lambda: np.zeros(n, dtype=np.uint8),
         "motifs 16-64 B x <80": lambda: motif(16, 64, 80),
@@ -104,6 +215,7 @@ def main():
         ok = v.value == n and np.array_equal(out[:n], data)
         if only:   # sequences in the first chunks: token count by walking the blocks on the host
             seqs, walked = count_sequences(stream[: w.value], 8)
+            batch_census(stream[: w.value], 8)
             print(f"   first chunks: {seqs} sequences in {walked} decoded bytes = {walked / max(seqs, 1):.1f} B per sequence")
         k = min(ms)
         print(f"{name:30s} ratio {n / w.value:8.2f}  decode {k:6.3f} ms  {(n + w.value) / k / 1e6:8.1f} GB/s (in+out)  "
