@@ -211,3 +211,85 @@ def test_mcdf_batch_matches_single_and_oracle(snappy, oracle):
         for (paths, _), st, h in zip(ref["data"]["Files"], ref["statuses"], hx):
             if st == oracle.FILE_HASHED and paths:
                 assert h in ref["blobs"]
+
+
+def _random_sequences(rng, n_seq, max_lit, max_match, max_off, overlap_share):
+    """Hand-built sequences: (literals, offset, match_len) with every length and offset drawn
+    independently, so that extension bytes, repeating patterns and far offsets all occur."""
+    parts, produced = [], 0
+    for _ in range(n_seq):
+        lit = int(rng.integers(0, max_lit + 1))
+        if produced + lit == 0:
+            lit = 1
+        ml = int(rng.integers(4, max_match + 1))
+        reach = min(produced + lit, max_off)
+        if rng.random() < overlap_share:
+            off = int(rng.integers(1, min(reach, 70) + 1))      # may repeat a short pattern
+        else:
+            off = int(rng.integers(min(ml, reach), reach + 1))
+        parts.append((bytes(rng.integers(0, 256, size=lit, dtype=np.uint8)), off, ml))
+        produced += lit + ml
+    parts.append((b"the end of it", None, None))
+    return parts
+
+
+@pytest.mark.parametrize("max_lit,max_match,max_off,overlap_share", [
+    (24, 36, 65535, 0.0),      # what a compressor makes of textures: short runs, offsets anywhere
+    (8, 20, 2048, 0.0),        # everything within reach of the recent output
+    (30, 40, 65535, 0.3),      # with repeating patterns of 1..70 bytes
+    (300, 300, 65535, 0.1),    # lengths on both sides of every limit
+    (3, 8, 64, 0.5),           # nothing but tiny pieces
+])
+def test_dense_short_sequences(snappy, oracle, max_lit, max_match, max_off, overlap_share):
+    rng = np.random.default_rng(max_lit * 1000 + max_match)
+    stream, want = b"", b""
+    for n_seq in (1, 5, 63, 64, 65, 700, 2500):
+        blk, out = H.block(_random_sequences(rng, n_seq, max_lit, max_match, max_off, overlap_share))
+        if len(blk) > len(out):
+            continue
+        stream += H.chunk(blk, len(out), True)
+        want += out
+    st_o, got_o = oracle.lz4net_decode(stream)
+    assert st_o == 0 and got_o == want
+    st, got = _gpu_decode(snappy, stream)
+    assert st == 0
+    assert got == want
+
+
+def test_dense_short_sequences_at_every_limit(snappy, oracle):
+    """One sequence of each combination of boundary lengths and offsets, surrounded by plain ones."""
+    rng = np.random.default_rng(11)
+    filler = lambda: (bytes(rng.integers(0, 256, size=9, dtype=np.uint8)), 7, 6)
+    parts = [(bytes(rng.integers(0, 256, size=20000, dtype=np.uint8)), 100, 50)] + [filler() for _ in range(70)]
+    produced = 20050 + 70 * 15
+    for lit in (0, 1, 14, 15, 16, 239, 240, 241, 269, 270, 271, 600):
+        for ml in (4, 18, 19, 20, 254, 255, 256, 273, 274, 700):
+            for off in (1, 3, 4, 15, 16, 17, ml - 1, ml, ml + 1, 4095, 4096, 4097, 8191, 8192, 8193, 12288, 16384):
+                if off < 1:
+                    continue
+                parts.append((bytes(rng.integers(0, 256, size=lit, dtype=np.uint8)), off, ml))
+                parts += [filler() for _ in range(int(rng.integers(0, 4)))]
+    parts.append((b"closing literals", None, None))
+    blk, out = H.block(parts)
+    stream = H.chunk(blk, len(out), True)
+    st_o, got_o = oracle.lz4net_decode(stream)
+    assert st_o == 0 and got_o == out
+    st, got = _gpu_decode(snappy, stream)
+    assert st == 0
+    assert got == out
+
+
+def test_dense_short_sequences_corrupted(snappy, oracle):
+    """Byte flips in a stream of short sequences: same verdict as the oracle, same bytes when accepted."""
+    rng = np.random.default_rng(21)
+    blk, out = H.block(_random_sequences(rng, 900, 24, 36, 65535, 0.2))
+    stream = H.chunk(blk, len(out), True)
+    for _ in range(150):
+        s = bytearray(stream)
+        pos = int(rng.integers(4, len(s)))
+        s[pos] ^= 1 << int(rng.integers(0, 8))
+        want_st, want = oracle.lz4net_decode(bytes(s))
+        st, got = _gpu_decode(snappy, bytes(s))
+        assert st == want_st, pos
+        if st == 0:
+            assert got == want, pos
