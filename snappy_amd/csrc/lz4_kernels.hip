@@ -597,17 +597,35 @@ __device__ __forceinline__ uint32_t take_batch(InputWindow &win, uint8_t *dst, u
         waiting = waiting && !far;
     }
 
-    // Then, in rounds, those that read the ring.  A match that repeats a pattern
-    // (offset < length) needs the pattern only; each step reads what the steps
-    // before it wrote, LDS operations of one wave taking effect in order.
-    const uint32_t need = off < my_ml ? off : my_ml;
+    // Then those that read the ring, in rounds: a match is copied once every match
+    // whose output it reads has been.  These are the sequences from the one that
+    // holds the source's first byte to the last one whose match begins before the
+    // source ends (output positions grow with the lane number); a source inside
+    // literals alone depends on nothing.  A match that repeats a pattern (offset
+    // < length) needs the pattern only; each copy step reads what the steps before
+    // it wrote, LDS operations of one wave taking effect in order.
+    const uint32_t need_end = s + (off < my_ml ? off : my_ml);
+    const uint32_t sorted_end = mine ? out_end : 0xFFFFFFFFu;
+    const uint32_t sorted_mo = mine ? mo : 0xFFFFFFFFu;
+    uint32_t dep_first = 0, dep_count = 0;  // lanes with out_end <= s; lanes with mo < need_end
+#pragma unroll
+    for (uint32_t step = 32; step != 0; step >>= 1) {
+        const uint32_t e = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(
+            static_cast<int>((dep_first + step - 1u) << 2), static_cast<int>(sorted_end)));
+        const uint32_t m = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(
+            static_cast<int>((dep_count + step - 1u) << 2), static_cast<int>(sorted_mo)));
+        dep_first += (e <= s) ? step : 0u;
+        dep_count += (m < need_end) ? step : 0u;
+    }
+    // Bits dep_first .. dep_count - 1 (both at most 63: the lane's own output lies behind its source).
+    const uint64_t below_count = (uint64_t(1) << dep_count) - 1u;
+    const uint64_t below_first = (uint64_t(1) << dep_first) - 1u;
+    const uint64_t depends_on = below_count & ~below_first;
     for (;;) {
         const uint64_t left = __builtin_amdgcn_ballot_w64(waiting);
         if (left == 0 || (tuning & kPhaseSwitches & 8u))
             break;
-        const uint32_t front = __builtin_amdgcn_readlane(mo, static_cast<uint32_t>(__builtin_ctzll(left)));
-        // (A source inside the sequence's own literals is final from the start.)
-        const bool go = waiting && (s + need <= front || s >= my_op);
+        const bool go = waiting && (depends_on & left) == 0;
         const uint32_t len = go ? my_ml : 0u;
         for (uint32_t t = 0; __builtin_amdgcn_ballot_w64(t < len) != 0; t += 4u * kMatchStep) {
             uint32_t w[kMatchStep];
