@@ -430,7 +430,7 @@ constexpr uint32_t kPhaseSwitches = 0xEu;
 constexpr uint32_t kPhaseSwitches = 0u;
 #endif
 constexpr uint32_t kBatchMatch = 255;
-constexpr uint32_t kBatchSpan = 4096;   // most output one batch produces
+constexpr uint32_t kBatchSpan = 6144;   // most output one batch produces; the ring keeps kHist - kBatchSpan bytes from before it
 constexpr uint32_t kBatchInput = 512;   // staged bytes a sequence may touch from its token on
 constexpr uint32_t kLitStep = 8;        // dwords a lane has in flight per step when copying literals
 constexpr uint32_t kMatchStep = 4;      // and matches: a match may repeat a pattern of 16 bytes or more
