@@ -293,3 +293,18 @@ def test_dense_short_sequences_corrupted(snappy, oracle):
         assert st == want_st, pos
         if st == 0:
             assert got == want, pos
+
+
+def test_one_sequence_at_a_time_path():
+    """The same block and stream tests with the batch path switched off (the switch is read once per
+    process, hence the child): both ways through the decoder stay covered."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("SNAPPY_LZ4_TUNING"):
+        pytest.skip("already the child")
+    env = dict(os.environ, SNAPPY_LZ4_TUNING="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-p", "no:cacheprovider", __file__, "-k",
+                        "dense or vectors or golden or framing or generated or corruptions"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
