@@ -144,7 +144,33 @@ def asset_like_bytes(n: int, rng: np.random.Generator) -> np.ndarray:
     return np.concatenate(parts)[:n]
 
 
-def make_mcdf_archive(payload_bytes: int, n_files: int, rng: np.random.Generator, tag: str):
+_DENSE_UNITS = {}
+
+
+def dense_bytes(n: int, rng: np.random.Generator, max_lit: int = 24, max_match: int = 36,
+                max_off: int = 65535) -> np.ndarray:
+    """What a compressor makes of textures and meshes: short literal runs between short copies of
+    earlier bytes, i.e. LZ4 streams of short sequences.  16 different 1 MiB chunks, repeated (the
+    1 MiB chunks of an lz4net stream are compressed independently)."""
+    key = (max_lit, max_match, max_off)
+    if key in _DENSE_UNITS:   # generated once per process (a Python loop per sequence)
+        unit = _DENSE_UNITS[key]
+        return np.tile(unit, -(-n // unit.size))[:n]
+    chunks = []
+    for _ in range(16):
+        buf = bytearray(rng.integers(0, 256, size=64, dtype=np.uint8).tobytes())
+        while len(buf) < (1 << 20):
+            buf += rng.integers(0, 256, size=int(rng.integers(0, max_lit + 1)), dtype=np.uint8).tobytes()
+            ml = int(rng.integers(4, min(max_match, len(buf)) + 1))
+            off = int(rng.integers(ml, min(len(buf), max_off) + 1))
+            buf += buf[len(buf) - off: len(buf) - off + ml]
+        chunks.append(np.frombuffer(bytes(buf[: 1 << 20]), dtype=np.uint8))
+    unit = _DENSE_UNITS[key] = np.concatenate(chunks)
+    return np.tile(unit, -(-n // unit.size))[:n]
+
+
+def make_mcdf_archive(payload_bytes: int, n_files: int, rng: np.random.Generator, tag: str,
+                      content: str = "asset"):
     """One synthetic MCDF archive: header JSON + file bodies, lz4net-framed in 1 MiB chunks
     by the library's own compressor (snappy_lz4net_encode).  Returns (stream bytes as uint8
     array, decoded payload size, payload)."""
@@ -159,7 +185,7 @@ def make_mcdf_archive(payload_bytes: int, n_files: int, rng: np.random.Generator
            "Files": [{"GamePaths": [f"chara/{tag}/f{i}.tex"], "Length": int(sz)} for i, sz in enumerate(sizes)]}
     js = _json.dumps(obj, separators=(",", ":")).encode()
     head = b"MCDF\x01" + struct.pack("<i", len(js)) + js
-    body = asset_like_bytes(payload_bytes, rng)
+    body = dense_bytes(payload_bytes, rng) if content == "dense" else asset_like_bytes(payload_bytes, rng)
     payload = np.concatenate([np.frombuffer(head, dtype=np.uint8), body])
     L = native.lib()
     cap = ctypes.c_uint64(0)
@@ -187,7 +213,8 @@ def run_mcdf(args, rank, world, local_rank, dist):
     n_arch = max(1, int(args.archives))
     streams, sizes, first_payload = [], [], None
     for a in range(n_arch):
-        st, size, payload = make_mcdf_archive(int(args.archive_mib * (1 << 20)), 100, rng, f"r{rank}a{a}")
+        st, size, payload = make_mcdf_archive(int(args.archive_mib * (1 << 20)), 100, rng, f"r{rank}a{a}",
+                                              getattr(args, "mcdf_content", "asset"))
         streams.append(st)
         sizes.append(size)
         if a == 0:
@@ -257,11 +284,13 @@ def run_mcdf(args, rank, world, local_rank, dist):
         "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "config": {"workload": f"{n_arch} MCDF archives of {args.archive_mib} MiB per GPU: lz4net decode + slice + SHA-1, "
                                "compressed streams start in host memory (PCIe copy inside the step)",
+                   "content": getattr(args, "mcdf_content", "asset"),
                    "compressed_bytes_per_gpu": comp_bytes, "decoded_bytes_per_gpu": out_bytes,
                    "ratio": out_bytes / comp_bytes},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": measured_traffic("mcdf", 1.0) if (n_arch, args.archive_mib) == (8, 256.0) else None,
+                     "traffic": measured_traffic("mcdf", 1.0)
+                     if (n_arch, args.archive_mib, getattr(args, "mcdf_content", "asset")) == (8, 256.0, "asset") else None,
                      "kernel": "lz4_decode_kernel",
                      "kernel_ms": k_lz4, "algorithmic_bytes_per_launch": algo,
                      "sha1_kernel_ms": float(np.mean(sha_ms))},
@@ -566,6 +595,9 @@ def main():
     ap.add_argument("--workload", default="blobs", choices=["blobs", "small", "folder", "corpus", "mcdf"])
     ap.add_argument("--archives", type=int, default=8, help="mcdf workload: archives per GPU")
     ap.add_argument("--archive-mib", type=float, default=128.0, help="mcdf workload: decoded MiB per archive")
+    ap.add_argument("--mcdf-content", default="asset", choices=["asset", "dense"],
+                    help="mcdf workload: file bodies of long runs (random, zeros, repeated motifs) or of dense "
+                         "short LZ4 sequences (short literal runs between short copies)")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink or grow the corpus")
     ap.add_argument("--strong", action="store_true",
                     help="one corpus for the whole job, sharded by file over the ranks (default: every "

@@ -169,18 +169,7 @@ def main():
         return np.tile(np.concatenate(parts)[:unit], n // unit)
 
     def lz_like(max_lit, max_match, max_off):
-        """Short literal runs and short copies of earlier bytes, as a compressor finds them in
-        textures and meshes; 16 different 1 MiB chunks, repeated."""
-        chunks = []
-        for _ in range(16):
-            buf = bytearray(rng.integers(0, 256, size=64, dtype=np.uint8).tobytes())
-            while len(buf) < (1 << 20):
-                buf += rng.integers(0, 256, size=int(rng.integers(0, max_lit + 1)), dtype=np.uint8).tobytes()
-                ml = int(rng.integers(4, min(max_match, len(buf)) + 1))
-                off = int(rng.integers(ml, min(len(buf), max_off) + 1))
-                buf += buf[len(buf) - off: len(buf) - off + ml]
-            chunks.append(np.frombuffer(bytes(buf[: 1 << 20]), dtype=np.uint8))
-        return np.tile(np.concatenate(chunks), n // (16 << 20))
+        return bench.dense_bytes(n, rng, max_lit, max_match, max_off)
 
     kinds = {
         "lz-like lit<=24 match<=36": lambda: lz_like(24, 36, 65535),
