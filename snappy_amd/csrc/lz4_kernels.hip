@@ -6,14 +6,16 @@
 // LZ4 blocks (or stored bytes), so one wavefront owns one chunk at a time and
 // draws chunks from a device queue.
 //
-// Inside a chunk the token stream is serial.  The wave keeps a 256-byte window
-// of the compressed input spread over its 64 lanes (one dword per lane) and
-// parses tokens on the scalar unit with v_readlane, so parsing never waits on
-// memory except to slide the window.  Literal and match copies are done by all
-// 64 lanes with consecutive lanes on consecutive bytes.  A match whose offset
-// is smaller than its length repeats a pattern of `offset` bytes; it is copied
-// as out[op+i] = out[op-offset + i mod offset], which reads only bytes written
-// by earlier sequences, so every lane can go at once.
+// Inside a chunk the token stream is serial.  Compressed bytes are staged in
+// LDS and parsed out of a 256-byte window spread over the wave's 64 lanes (one
+// dword per lane, v_readlane), so parsing waits on memory once per 8 KiB.
+//
+// Long sequences are copied one at a time by all 64 lanes, consecutive lanes on
+// consecutive bytes.  A match whose offset is smaller than its length repeats a
+// pattern of `offset` bytes; it is copied as out[op+i] = out[op-offset + i mod
+// offset], which reads only bytes written by earlier sequences, so every lane
+// can go at once.  Runs of short sequences are taken up to 64 at a time, one
+// sequence per lane (take_batch below).
 //
 // Acceptance rules are those of the decoder lz4net ports (LZ4 r7x
 // LZ4_uncompress with a known output length): a literal run that ends within 8
