@@ -26,6 +26,7 @@
 #include "lz4_launch.hpp"
 #include "wave_util.hpp"
 
+#include <cstdio>
 #include <cstdlib>
 
 namespace snappy {
@@ -126,7 +127,7 @@ struct InputWindow {
     __device__ __forceinline__ uint32_t peek32(uint32_t pos, uint32_t lane)
     {
         uint32_t di = (pos >> 2) - first;
-        if (di >= 63u) {  // also catches positions before the window
+        if (__builtin_expect(di >= 63u, 0)) {  // also catches positions before the window
             slide(pos, lane);
             di = 0;
         }
@@ -428,8 +429,22 @@ constexpr uint32_t kBatchLit = 240;
 // (tuning bits 1-3; the output is then wrong) to see what each costs.
 #ifdef SNAPPY_LZ4_PHASE_SWITCHES
 constexpr uint32_t kPhaseSwitches = 0xEu;
+__device__ unsigned long long g_phase_cycles[8];
+struct PhaseClock {
+    uint64_t last;
+    uint64_t acc[8];
+    __device__ void start() { last = __builtin_amdgcn_s_memtime(); for (int i = 0; i < 8; ++i) acc[i] = 0; }
+    __device__ void mark(int phase) { const uint64_t now = __builtin_amdgcn_s_memtime(); acc[phase] += now - last; last = now; }
+    __device__ void flush(uint32_t lane) { if (lane == 0) for (int i = 0; i < 8; ++i) atomicAdd(&g_phase_cycles[i], acc[i]); }
+};
+#define PHASE_MARK(clock, phase) (clock).mark(phase)
 #else
 constexpr uint32_t kPhaseSwitches = 0u;
+struct PhaseClock {
+    __device__ void start() {}
+    __device__ void flush(uint32_t) {}
+};
+#define PHASE_MARK(clock, phase) ((void)0)
 #endif
 constexpr uint32_t kBatchMatch = 255;
 constexpr uint32_t kBatchSpan = 6144;   // most output one batch produces; the ring keeps kHist - kBatchSpan bytes from before it
@@ -474,8 +489,9 @@ __device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v)
 __device__ __forceinline__ uint32_t take_batch(InputWindow &win, uint8_t *dst, uint8_t *ring,
                                                uint32_t &ip_io, uint32_t &op_io, uint32_t valid_from,
                                                uint32_t iend, uint32_t oend, uint32_t &walk,
-                                               uint32_t lane, uint32_t tuning)
+                                               uint32_t lane, uint32_t tuning, PhaseClock &clk)
 {
+    PHASE_MARK(clk, 5);
     uint32_t ip = ip_io;  // uniform
     const uint32_t start = op_io;
     const bool likely = walk >= 16u;  // recent batches were worth their while
@@ -489,29 +505,28 @@ __device__ __forceinline__ uint32_t take_batch(InputWindow &win, uint8_t *dst, u
     }
     const uint32_t stage_end = win.stage_end();
 
+    PHASE_MARK(clk, 6);
     // Where the tokens start.
     uint32_t n = 0;
     uint32_t my_ip = 0;  // lane j: sequence j
-    while (n < walk && ip + kBatchInput <= stage_end) {
+    // Only what the next token's position depends on is looked at here: the token
+    // and the literal run's extension byte.  Longer extensions make the positions
+    // from there on meaningless; the lanes find that out below and the batch ends
+    // in front of such a sequence.
+    const uint32_t ip_limit = stage_end - kBatchInput;  // at least kJumpBlocks blocks are staged
+    while (ip <= ip_limit) {
         const uint32_t r = uni(win.peek32(ip, lane));
         const uint32_t lit = (r >> 4) & 15u;
-        uint32_t len = 3u + lit;
-        if (lit == 15u) {
-            const uint32_t more = (r >> 8) & 255u;
-            if (more > kBatchLit - 15u)
-                break;
-            len += 1u + more;
-        }
-        if ((r & 15u) == 15u) {
-            const uint32_t more = uni(win.peek32(ip + len, lane)) & 255u;
-            if (more > kBatchMatch - 19u)
-                break;
-            len += 1u;
-        }
+        uint32_t len = 3u + lit + ((r & 15u) == 15u ? 1u : 0u);
+        if (lit == 15u)
+            len += 1u + ((r >> 8) & 255u);
         my_ip = (lane == n) ? ip : my_ip;
         ++n;
         ip += len;
+        if (__builtin_expect(n >= walk, 0))
+            break;
     }
+    PHASE_MARK(clk, 0);
     if (n == 0) {
         walk = 4;
         return 0;
@@ -555,6 +570,7 @@ __device__ __forceinline__ uint32_t take_batch(InputWindow &win, uint8_t *dst, u
     ip_io = take < n ? __builtin_amdgcn_readlane(my_ip, take) : ip;
     op_io = __builtin_amdgcn_readlane(out_end, take - 1u);
 
+    PHASE_MARK(clk, 1);
     const bool mine = lane < take;
     const uint32_t my_lit = mine ? lit : 0u;
     const uint32_t my_ml = mine ? ml : 0u;
@@ -577,6 +593,7 @@ __device__ __forceinline__ uint32_t take_batch(InputWindow &win, uint8_t *dst, u
         }
     }
 
+    PHASE_MARK(clk, 2);
     // Matches are written to the byte: what follows a match is already in place.
     // First those whose source is older than the batch and out of the ring's reach.
     // Every lane loads, from a harmless address when it has nothing to copy, so
@@ -599,6 +616,7 @@ __device__ __forceinline__ uint32_t take_batch(InputWindow &win, uint8_t *dst, u
         waiting = waiting && !far;
     }
 
+    PHASE_MARK(clk, 3);
     // Then those that read the ring, in rounds: a match is copied once every match
     // whose output it reads has been.  These are the sequences from the one that
     // holds the source's first byte to the last one whose match begins before the
@@ -641,13 +659,14 @@ __device__ __forceinline__ uint32_t take_batch(InputWindow &win, uint8_t *dst, u
         }
         waiting = waiting && !go;
     }
+    PHASE_MARK(clk, 4);
     return take;
 }
 
 // Decodes one compressed chunk; returns true when the block is well-formed.
 __device__ bool decode_block(const uint8_t *__restrict__ in_base, uint64_t in_alloc,
                              const Lz4Chunk &ck, uint8_t *out_base, uint8_t *ring, uint32_t *stage,
-                             uint32_t lane, uint32_t tuning)
+                             uint32_t lane, uint32_t tuning, PhaseClock &clk)
 {
     const uint8_t *src = in_base + ck.in_off;
     uint8_t *dst = out_base + ck.out_off;
@@ -666,11 +685,20 @@ __device__ bool decode_block(const uint8_t *__restrict__ in_base, uint64_t in_al
     uint32_t op = 0;         // uniform
     uint32_t valid_from = 0; // uniform: the ring holds output positions [valid_from, op)
     uint32_t walk = kWave;   // uniform: tokens the next batch looks at
+    uint32_t misses = 0, skip = 0;  // uniform: back-off of the batch attempts on streams of long sequences
     const uint8_t *src_al = src - in_shift;
 
     for (;;) {
-        if (!(tuning & 1u) && take_batch(win, dst, ring, ip, op, valid_from, iend, oend, walk, lane, tuning) >= 16u)
-            continue;  // more of the same is likely
+        if (skip != 0u) {
+            --skip;
+        } else if (!(tuning & 1u)) {
+            const uint32_t taken = take_batch(win, dst, ring, ip, op, valid_from, iend, oend, walk, lane, tuning, clk);
+            if (taken >= 16u)
+                continue;  // more of the same is likely
+            // Attempts that take nothing back off: 1, 3, 7, 15 sequences go by before the next one.
+            misses = taken != 0u ? 0u : (2u * misses + 1u < 15u ? 2u * misses + 1u : 15u);
+            skip = misses;
+        }
         if (ip >= iend)
             return false;
         uint32_t bytes = uni(win.peek32(ip, lane));
@@ -790,7 +818,11 @@ lz4_decode_kernel(const uint8_t *__restrict__ in_base, uint64_t in_alloc, uint8_
         const Lz4Chunk ck = chunks[i];
         bool ok = true;
         if (ck.compressed) {
-            ok = decode_block(in_base, in_alloc, ck, out_base, ring, stage, lane, tuning);
+            PhaseClock clk;
+            clk.start();
+            ok = decode_block(in_base, in_alloc, ck, out_base, ring, stage, lane, tuning, clk);
+            PHASE_MARK(clk, 5);
+            clk.flush(lane);
         } else {
             copy_run(out_base + ck.out_off, in_base + ck.in_off, ck.orig_len, lane);
         }
@@ -812,8 +844,19 @@ hipError_t launch_lz4_decode(const uint8_t *d_in, uint64_t in_alloc, uint8_t *d_
         const char *env = std::getenv("SNAPPY_LZ4_TUNING");
         return env ? static_cast<uint32_t>(std::strtoul(env, nullptr, 0)) : 0u;
     }();
+#ifdef SNAPPY_LZ4_PHASE_SWITCHES
+    unsigned long long zero[8] = {};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), zero, sizeof zero);
+#endif
     hipLaunchKernelGGL(lz4_decode_kernel, dim3(blocks), dim3(256), 0, stream, d_in, in_alloc, d_out,
                        d_chunks, n_chunks, d_queue, d_status, tuning);
+#ifdef SNAPPY_LZ4_PHASE_SWITCHES
+    (void)hipStreamSynchronize(stream);
+    unsigned long long c[8];
+    (void)hipMemcpyFromSymbol(c, HIP_SYMBOL(g_phase_cycles), sizeof c);
+    fprintf(stderr, "lz4 phases (s_memtime ticks summed over %u chunks): walk %llu classify %llu literals %llu "
+                    "old sources %llu rounds %llu one-at-a-time %llu staging %llu\n", n_chunks, c[0], c[1], c[2], c[3], c[4], c[5], c[6]);
+#endif
     return hipGetLastError();
 }
 
