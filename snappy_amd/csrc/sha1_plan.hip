@@ -106,18 +106,38 @@ __device__ __forceinline__ int path_for(double edge_blocks, double d_max, const 
     return 0;
 }
 
+constexpr int kPlanWaves = kPlanBuckets / 64;
+
+__device__ __forceinline__ double candidate_d(int c, double d_top, double max_blocks, double best_d,
+                                              const Sha1CostModel &m)
+{
+    if (c < kCoarseCandidates)
+        return d_top * exp2(-0.5 * static_cast<double>(c));
+    if (c == kCoarseCandidates)
+        return max_blocks * m.chain_ns[0] * 1.0001;
+    if (c < kCoarseCandidates + kOwnCandidates)
+        return max_blocks * m.chain_ns[c - kCoarseCandidates] * 0.9999;
+    return best_d * exp2((static_cast<double>(c - kCoarseCandidates - kOwnCandidates) -
+                          0.5 * (kFineCandidates - 1)) / kFineCandidates);
+}
+
 __global__ void __launch_bounds__(kPlanBuckets)
 plan_scan(Sha1PlanState *__restrict__ st, uint32_t n, Sha1CostModel m)
 {
     __shared__ uint32_t scan[kPlanBuckets];
-    __shared__ uint32_t used[kPlanBuckets];  // positions of the non-empty buckets
-    __shared__ float dur[kPlanBuckets];      // per used bucket, for the candidate at hand:
-    __shared__ uint32_t pieces[kPlanBuckets];  //   duration of a piece, number of pieces,
-    __shared__ double work[kPlanBuckets];      //   SIMD time
+    __shared__ uint32_t used[kPlanBuckets];   // positions of the non-empty buckets
+    __shared__ double u_edge[kPlanBuckets];   // per used bucket: largest file possible,
+    __shared__ double u_blocks[kPlanBuckets]; //   blocks in it,
+    __shared__ uint32_t u_files[kPlanBuckets];  // files in it
+    // Per wave, for the candidate the wave is working on: duration of a piece and
+    // number of pieces of every used bucket.
+    __shared__ float dur[kPlanWaves][kPlanBuckets];
+    __shared__ uint32_t pieces[kPlanWaves][kPlanBuckets];
+    __shared__ double cand_bound[kPlanCandidates], cand_d[kPlanCandidates];
     __shared__ uint32_t n_used;
-    __shared__ float d_late;   // duration of the first piece that has to wait for a SIMD
     __shared__ double best_bound, best_d;
     const uint32_t k = threadIdx.x;
+    const uint32_t lane = k & 63u, wave = k >> 6;
     const uint32_t count = st->hist[k];
     scan[k] = count;
     if (k == 0)
@@ -137,75 +157,85 @@ plan_scan(Sha1PlanState *__restrict__ st, uint32_t n, Sha1CostModel m)
     const double max_blocks = static_cast<double>(st->max_blocks);
     const double simds = static_cast<double>(m.n_simd);
     const uint32_t u_count = n_used;
-    const uint32_t pos = k < u_count ? used[k] : 0u;
-    const double edge = fmin(bucket_floor(kPlanBuckets - pos), max_blocks);  // largest file possible
-    const double blocks = k < u_count ? static_cast<double>(st->blocks[pos]) : 0.0;
-    const uint32_t files = k < u_count ? st->hist[pos] : 0u;
+    if (k < u_count) {
+        const uint32_t pos = used[k];
+        u_edge[k] = fmin(bucket_floor(kPlanBuckets - pos), max_blocks);
+        u_blocks[k] = static_cast<double>(st->blocks[pos]);
+        u_files[k] = st->hist[pos];
+    }
+    if (k == 0) {
+        best_bound = -1.0;
+        best_d = 0.0;
+    }
+    __syncthreads();
 
     if (m.forced_path < 0) {
-        if (k == 0) {
-            best_bound = -1.0;
-            best_d = 0.0;
-        }
         // Coarse pass: from "everything may take the slowest path" down by sqrt(2)
         // per step; then the largest file's own thresholds (just below them it moves
         // to the next faster path while everything else keeps the most room); then a
-        // fine pass around the best so far.
+        // fine pass around the best so far.  Each wave of the workgroup weighs one
+        // candidate at a time; the choice among them is made in candidate order.
         const double d_top = max_blocks * m.chain_ns[kSha1Paths - 1] * 1.0001;
         // With no more files than SIMDs every piece starts at once, the batch lasts as
         // long as its largest file on the fastest path, and the cheapest plan is to
         // let everything else take that long too: one candidate settles it.
         const bool one_round = n <= m.n_simd;
-        for (int c = one_round ? kCoarseCandidates : 0;
-             c < (one_round ? kCoarseCandidates + 1 : kPlanCandidates); ++c) {
-            double d_max;
-            if (c < kCoarseCandidates)
-                d_max = d_top * exp2(-0.5 * static_cast<double>(c));
-            else if (c == kCoarseCandidates)
-                d_max = max_blocks * m.chain_ns[0] * 1.0001;
-            else if (c < kCoarseCandidates + kOwnCandidates)
-                d_max = max_blocks * m.chain_ns[c - kCoarseCandidates] * 0.9999;
-            else
-                d_max = best_d * exp2((static_cast<double>(c - kCoarseCandidates - kOwnCandidates) -
-                                       0.5 * (kFineCandidates - 1)) / kFineCandidates);
-            if (k < u_count) {
-                const int path = path_for(edge, d_max, m);
-                const uint32_t per_wave = 64u / static_cast<uint32_t>(kHopGroupLanes[path]);
-                dur[k] = static_cast<float>(edge * m.chain_ns[path]);
-                pieces[k] = (files + per_wave - 1) / per_wave;
-                work[k] = blocks * m.simd_ns[path];
+        for (int stage = 0; stage < (one_round ? 1 : 2); ++stage) {
+            const int c_lo = one_round ? kCoarseCandidates : (stage == 0 ? 0 : kCoarseCandidates + kOwnCandidates);
+            const int c_hi = one_round ? kCoarseCandidates + 1
+                                       : (stage == 0 ? kCoarseCandidates + kOwnCandidates : kPlanCandidates);
+            for (int c0 = c_lo; c0 < c_hi; c0 += kPlanWaves) {
+                const int c = c0 + static_cast<int>(wave);
+                const bool on = c < c_hi;
+                const double d_max = candidate_d(on ? c : c_lo, d_top, max_blocks, best_d, m);
+                double total = 0.0;
+                float longest = 0.f;
+                for (uint32_t v = lane; on && v < u_count; v += 64u) {
+                    const double edge = u_edge[v];
+                    const int path = path_for(edge, d_max, m);
+                    const uint32_t per_wave = 64u / static_cast<uint32_t>(kHopGroupLanes[path]);
+                    const float d = static_cast<float>(edge * m.chain_ns[path]);
+                    dur[wave][v] = d;
+                    pieces[wave][v] = (u_files[v] + per_wave - 1) / per_wave;
+                    total += u_blocks[v] * m.simd_ns[path];
+                    longest = fmaxf(longest, d);
+                }
+                __syncthreads();
+                // Duration of the first piece that has to wait for a SIMD.
+                float late = 0.f;
+                for (uint32_t v = lane; on && v < u_count; v += 64u) {
+                    const float mine = dur[wave][v];
+                    uint32_t before = 0;  // pieces handed out before this bucket's
+                    for (uint32_t x = 0; x < u_count; ++x) {
+                        const float dx = dur[wave][x];
+                        if (dx > mine || (dx == mine && x < v))
+                            before += pieces[wave][x];
+                    }
+                    if (before <= m.n_simd && m.n_simd < before + pieces[wave][v])
+                        late = mine;
+                }
+                for (int sh = 32; sh > 0; sh >>= 1) {
+                    total += __shfl_xor(total, sh);
+                    longest = fmaxf(longest, __shfl_xor(longest, sh));
+                    late = fmaxf(late, __shfl_xor(late, sh));
+                }
+                if (on && lane == 0) {
+                    // The busier the chip, the lower its clock: scale the chains by the
+                    // share of SIMD time in use.
+                    const double load = total / simds;
+                    const double first = fmax(static_cast<double>(longest), load + static_cast<double>(late));
+                    const double slow = 1.0 + m.load_slowdown * fmin(1.0, load / first);
+                    cand_bound[c] = fmax(static_cast<double>(longest) * slow, load + static_cast<double>(late) * slow);
+                    cand_d[c] = d_max;
+                }
+                __syncthreads();
             }
-            if (k == 0)
-                d_late = 0.f;
-            __syncthreads();
-            if (k < u_count) {
-                // Pieces that are handed out before this bucket's.
-                uint32_t before = 0;
-                const float mine = dur[k];
-                for (uint32_t v = 0; v < u_count; ++v)
-                    if (dur[v] > mine || (dur[v] == mine && v < k))
-                        before += pieces[v];
-                if (before <= m.n_simd && m.n_simd < before + pieces[k])
-                    d_late = mine;
-            }
-            __syncthreads();
             if (k == 0) {
-                double total = 0.0, longest = 0.0;
-                for (uint32_t v = 0; v < u_count; ++v) {
-                    total += work[v];
-                    longest = fmax(longest, static_cast<double>(dur[v]));
-                }
-                // The busier the chip, the lower its clock: scale the chains by the
-                // share of SIMD time in use.
-                const double load = total / simds;
-                const double first = fmax(longest, load + static_cast<double>(d_late));
-                const double slow = 1.0 + m.load_slowdown * fmin(1.0, load / first);
-                const double bound = fmax(longest * slow, load + static_cast<double>(d_late) * slow);
-                // Move on only for a clear gain.
-                if (best_bound < 0.0 || bound < 0.98 * best_bound) {
-                    best_bound = bound;
-                    best_d = d_max;
-                }
+                for (int c = c_lo; c < c_hi; ++c)
+                    if (best_bound < 0.0 || cand_bound[c] < 0.98 * best_bound) {  // move on only for a clear gain
+                        best_bound = cand_bound[c];
+                        best_d = cand_d[c];
+                    }
             }
             __syncthreads();
         }
