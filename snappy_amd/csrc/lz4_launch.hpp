@@ -23,7 +23,7 @@ struct Lz4Chunk {
 // *d_queue must be zero at launch; d_status[i] receives 0 (ok) or 1 (corrupt).
 hipError_t launch_lz4_decode(const uint8_t *d_in, uint64_t in_alloc, uint8_t *d_out,
                              const Lz4Chunk *d_chunks, uint32_t n_chunks, uint32_t *d_queue,
-                             uint32_t *d_status, int blocks, hipStream_t stream);
+                             uint32_t *d_status, int n_cu, hipStream_t stream);
 
 // One chunk to compress: in_len bytes at d_in + in_off; the block is written at
 // d_out + out_off, where in_len + in_len / 255 + 16 bytes must be available.

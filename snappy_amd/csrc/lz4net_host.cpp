@@ -162,14 +162,11 @@ int decode_streams_on_device(SlotLease &lease, std::vector<StreamJob> &jobs)
     const bool prof = profiling_enabled();
     if (prof)
         SNAPPY_HIP_TRY(hipEventRecord(s.ev_prof[1][0], stream));
-    // One wave per chunk in flight; four waves per workgroup.
-    const int blocks = static_cast<int>(std::min<uint64_t>(
-        (n_chunks + 3) / 4, static_cast<uint64_t>(lease.dev->n_cu) * 8u));
     SNAPPY_HIP_TRY(launch_lz4_decode(arena, in_alloc, arena,
                                      static_cast<const Lz4Chunk *>(s.d_tasks.ptr),
                                      static_cast<uint32_t>(n_chunks),
                                      static_cast<uint32_t *>(s.d_misc.ptr),
-                                     static_cast<uint32_t *>(s.d_out.ptr), blocks, stream));
+                                     static_cast<uint32_t *>(s.d_out.ptr), lease.dev->n_cu, stream));
     if (prof)
         SNAPPY_HIP_TRY(hipEventRecord(s.ev_prof[1][1], stream));
     // The status words must be on the host before the staging buffer is reused.
