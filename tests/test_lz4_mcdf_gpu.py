@@ -308,3 +308,33 @@ def test_one_sequence_at_a_time_path():
                         "dense or vectors or golden or framing or generated or corruptions"],
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_concurrent_decoders(snappy, oracle):
+    """Four threads decode different streams at the same time (the plugin's draw thread and a
+    thread-pool task may overlap); every result must be its own stream's."""
+    import threading
+    streams, wants = [], []
+    for seed in range(4):
+        rng = np.random.default_rng(100 + seed)
+        blk, out = H.block(_random_sequences(rng, 1500 + 300 * seed, 24, 36, 65535, 0.2))
+        data = H.asset_like(400_000 + 50_000 * seed, seed)
+        streams.append(H.chunk(blk, len(out), True) + oracle.lz4net_encode(data, chunk_size=65536))
+        wants.append(out + data)
+    errors = []
+
+    def work(i):
+        try:
+            for _ in range(8):
+                st, got = _gpu_decode(snappy, streams[i])
+                if st != 0 or got != wants[i]:
+                    errors.append((i, st))
+        except Exception as e:  # noqa: BLE001
+            errors.append((i, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
