@@ -17,6 +17,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstring>
 #include <ctime>
@@ -32,6 +33,7 @@
 #include "../../include/snappyhash.h"
 #include "mcdf_host.hpp"
 #include "runtime.hpp"
+#include "sha1_api.hpp"
 
 namespace fs = std::filesystem;
 
@@ -308,6 +310,52 @@ bool read_exact(const char *path, uint8_t *dst, uint64_t size)
 // in one batch whose transfer overlaps the kernel, and the new <HASH>.dat files
 // are written by several threads.  Per entry the outcome is what the reference's
 // sequential loop produces.
+namespace {
+
+// Files being read into one arena by other threads: a transfer out of the arena
+// waits until the files it is about to send have been read.
+class ReadGate : public snappy::SourceGate {
+public:
+    ReadGate(const uint8_t *arena, const std::vector<uint64_t> &offsets, const std::vector<uint64_t> &sizes)
+        : arena_(arena), offsets_(offsets), sizes_(sizes), state_(offsets.size(), 0)
+    {
+    }
+
+    void finished(uint64_t k, bool ok)
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            state_[k] = ok ? 1 : 2;
+        }
+        cv_.notify_all();
+    }
+
+    bool readable(uint64_t k) const { return state_[k] == 1; }
+
+    void wait_for(const uint8_t *src, uint64_t len) override
+    {
+        if (len == 0 || src < arena_)
+            return;
+        const uint64_t lo = static_cast<uint64_t>(src - arena_), hi = lo + len;
+        // Offsets ascend: the first file that ends behind lo, up to the last that starts before hi.
+        size_t k = static_cast<size_t>(std::upper_bound(offsets_.begin(), offsets_.end(), lo) - offsets_.begin());
+        k = k ? k - 1 : 0;
+        std::unique_lock<std::mutex> lk(mu_);
+        for (; k < offsets_.size() && offsets_[k] < hi; ++k)
+            if (offsets_[k] + sizes_[k] > lo)
+                cv_.wait(lk, [&] { return state_[k] != 0; });
+    }
+
+private:
+    const uint8_t *arena_;
+    const std::vector<uint64_t> &offsets_, &sizes_;
+    std::vector<uint8_t> state_;  // 0 being read, 1 read, 2 unreadable
+    std::mutex mu_;
+    std::condition_variable cv_;
+};
+
+}  // namespace
+
 extern "C" int snappy_store_files(const char *const *paths, uint64_t n, const char *files_dir,
                                   char *hex, uint8_t *status)
 {
@@ -338,26 +386,40 @@ extern "C" int snappy_store_files(const char *const *paths, uint64_t n, const ch
     int st = arena.acquire(total + 256);
     if (st != SNAPPY_OK)
         return st;
-    // File.ReadAllBytes (:317), many files in flight.
-    std::vector<uint8_t> readable(owner.size(), 0);
-    parallel_for(owner.size(), [&](uint64_t k) {
-        readable[k] = read_exact(paths[owner[k]], arena.data() + offs[k], sizes[k]) ? 1 : 0;
-    });
-    std::vector<uint64_t> b_off, b_len, b_owner;
+    // File.ReadAllBytes (:317), many files in flight, largest first: that is the order
+    // in which the batch below sends them to the GPU, and it starts sending (and
+    // hashing) while the rest is still being read.
+    std::vector<uint64_t> by_size(owner.size());
     for (size_t k = 0; k < owner.size(); ++k)
-        if (readable[k]) {
+        by_size[k] = k;
+    std::stable_sort(by_size.begin(), by_size.end(),
+                     [&](uint64_t x, uint64_t y) { return sizes[x] > sizes[y]; });
+    ReadGate gate(arena.data(), offs, sizes);
+    std::thread reader([&] {
+        parallel_for(owner.size(), [&](uint64_t j) {
+            const uint64_t k = by_size[j];
+            gate.finished(k, read_exact(paths[owner[k]], arena.data() + offs[k], sizes[k]));
+        });
+    });
+    // Crypto.GetHash for all of them in one GPU batch (:318).
+    std::vector<uint8_t> all_digests(owner.size() * 20);
+    st = sha1_batch_gated(arena.data(), offs.data(), sizes.data(), owner.size(), all_digests.data(), &gate);
+    reader.join();
+    if (st != SNAPPY_OK)
+        return st;
+    // A file that could not be read in full is skipped like a missing one (its digest is of no use).
+    std::vector<uint64_t> b_off, b_len, b_owner;
+    std::vector<uint8_t> digests;
+    for (size_t k = 0; k < owner.size(); ++k)
+        if (gate.readable(k)) {
             b_off.push_back(offs[k]);
             b_len.push_back(sizes[k]);
             b_owner.push_back(owner[k]);
+            digests.insert(digests.end(), all_digests.begin() + 20 * k, all_digests.begin() + 20 * (k + 1));
             status[owner[k]] = 0;
         }
     if (b_owner.empty())
         return SNAPPY_OK;
-    // Crypto.GetHash for all of them in one GPU batch (:318).
-    std::vector<uint8_t> digests(b_owner.size() * 20);
-    st = snappy_sha1_batch(arena.data(), b_off.data(), b_len.data(), b_owner.size(), digests.data());
-    if (st != SNAPPY_OK)
-        return st;
     // `if (!File.Exists(hashedFilePath)) File.Copy(...)` (:457-466).  Entries with the
     // same digest have the same bytes: the first of them writes the file.
     std::map<std::string, size_t> first_with_hash;

@@ -203,7 +203,7 @@ uint64_t lay_out(const HostRange *ranges, uint64_t first, const std::vector<uint
 // Copy first, then hash: small batches, or no fine-grained memory for the
 // progress words.
 int hash_ranges_serial(SlotLease &lease, const HostRange *ranges, uint64_t first, uint64_t n,
-                       uint8_t *digests)
+                       uint8_t *digests, SourceGate *gate)
 {
     Slot &s = *lease.slot;
     std::vector<uint64_t> dev_off(n), lens(n);
@@ -217,7 +217,7 @@ int hash_ranges_serial(SlotLease &lease, const HostRange *ranges, uint64_t first
         return st;
     uint8_t *d_base = static_cast<uint8_t *>(s.d_data.ptr);
     SNAPPY_HIP_TRY(transfer_to_device(s, lease.dev->hip_device, pieces, kTransferSliceBytes, d_base,
-                                      nullptr, nullptr));
+                                      nullptr, nullptr, gate));
     return run_sha1_tables(lease, d_base, dev_off.data(), lens.data(), n, digests + 20 * first,
                            nullptr);
 }
@@ -230,7 +230,7 @@ int hash_ranges_serial(SlotLease &lease, const HostRange *ranges, uint64_t first
 // files whose chains decide the finishing time therefore start within
 // milliseconds, and the rest of the transfer hides behind them.
 int hash_ranges_overlapped(SlotLease &lease, const HostRange *ranges, uint64_t first, uint64_t n,
-                           uint64_t slice_bytes, uint8_t *digests)
+                           uint64_t slice_bytes, uint8_t *digests, SourceGate *gate)
 {
     Slot &s = *lease.slot;
     std::vector<uint64_t> dev_off(n), lens(n);
@@ -246,7 +246,7 @@ int hash_ranges_overlapped(SlotLease &lease, const HostRange *ranges, uint64_t f
     const uint64_t bytes = lay_out(ranges, first, order, dev_off, lens, pieces);
     const uint64_t n_slices = (bytes + slice_bytes - 1) / slice_bytes;
     if (n_slices == 0 || n_slices >= 0x7FFFFFFFull)
-        return hash_ranges_serial(lease, ranges, first, n, digests);
+        return hash_ranges_serial(lease, ranges, first, n, digests, gate);
 
     int st;
     const size_t table_bytes = n * sizeof(uint64_t);
@@ -290,7 +290,7 @@ int hash_ranges_overlapped(SlotLease &lease, const HostRange *ranges, uint64_t f
     if (const long delay_ms = env_long("SNAPPY_TEST_TRANSFER_DELAY_MS", 0))  // tests: a held-up transfer
         std::this_thread::sleep_for(std::chrono::milliseconds(delay_ms));
     hipError_t copy_error = transfer_to_device(s, lease.dev->hip_device, pieces, slice_bytes, d_base,
-                                               &d_arrival->arrived, slice_numbers);
+                                               &d_arrival->arrived, slice_numbers, gate);
     if (copy_error != hipSuccess) {
         set_error_detail(std::string("host to device transfer: ") + hipGetErrorString(copy_error));
         (void)hipGetLastError();
@@ -324,7 +324,7 @@ constexpr int kMaxHipDevices = 64;
 // Copies the ranges [first, last) into the slot's device arena and hashes them
 // on the slot's device.
 int hash_ranges_on_device(int device, const HostRange *ranges, uint64_t first, uint64_t last,
-                          uint8_t *digests)
+                          uint8_t *digests, SourceGate *gate)
 {
     SlotLease lease;
     int st = lease.acquire(device);
@@ -342,14 +342,14 @@ int hash_ranges_on_device(int device, const HostRange *ranges, uint64_t first, u
     const uint64_t slice = std::max<uint64_t>(
         256, static_cast<uint64_t>(env_long("SNAPPY_OVERLAP_SLICE_BYTES", 32L << 20)) & ~uint64_t(255));
     if (lease.slot->d_flags == nullptr || total < min_bytes)
-        return hash_ranges_serial(lease, ranges, first, n, digests);
+        return hash_ranges_serial(lease, ranges, first, n, digests, gate);
     // One waiting kernel per physical GPU at a time, for the same reason: a second
     // caller copies first and hashes afterwards.
     static std::atomic<bool> waiting_kernel[kMaxHipDevices];
     std::atomic<bool> &busy = waiting_kernel[lease.dev->hip_device % kMaxHipDevices];
     if (busy.exchange(true))
-        return hash_ranges_serial(lease, ranges, first, n, digests);
-    st = hash_ranges_overlapped(lease, ranges, first, n, slice, digests);
+        return hash_ranges_serial(lease, ranges, first, n, digests, gate);
+    st = hash_ranges_overlapped(lease, ranges, first, n, slice, digests, gate);
     busy.store(false);
     return st;
 }
@@ -378,7 +378,7 @@ namespace {
 
 // Files are independent, so a batch shards across devices with no exchange:
 // contiguous groups of near-equal byte count, one host thread per device.
-int hash_ranges(const std::vector<HostRange> &ranges, uint8_t *digests)
+int hash_ranges(const std::vector<HostRange> &ranges, uint8_t *digests, SourceGate *gate = nullptr)
 {
     const uint64_t n = ranges.size();
     if (n == 0)
@@ -398,7 +398,7 @@ int hash_ranges(const std::vector<HostRange> &ranges, uint8_t *digests)
         std::min<uint64_t>(std::min<uint64_t>(n, static_cast<uint64_t>(n_dev)),
                            std::max<uint64_t>(1, total / min_shard_bytes)));
     if (shards <= 1)
-        return hash_ranges_on_device(pick_device(), ranges.data(), 0, n, digests);
+        return hash_ranges_on_device(pick_device(), ranges.data(), 0, n, digests, gate);
 
     std::vector<uint64_t> lens(n);
     for (uint64_t i = 0; i < n; ++i)
@@ -412,7 +412,7 @@ int hash_ranges(const std::vector<HostRange> &ranges, uint8_t *digests)
             const uint64_t a = cut[static_cast<size_t>(d)], b = cut[static_cast<size_t>(d) + 1];
             if (b > a)
                 status[static_cast<size_t>(d)] =
-                    hash_ranges_on_device(d, ranges.data(), a, b, digests);
+                    hash_ranges_on_device(d, ranges.data(), a, b, digests, gate);
         });
     }
     for (auto &w : workers)
@@ -424,6 +424,19 @@ int hash_ranges(const std::vector<HostRange> &ranges, uint8_t *digests)
 }
 
 }  // namespace
+}  // namespace snappy
+
+namespace snappy {
+
+int sha1_batch_gated(const uint8_t *base, const uint64_t *offsets, const uint64_t *lengths, uint64_t n,
+                     uint8_t *digests, SourceGate *gate)
+{
+    std::vector<HostRange> r(n);
+    for (uint64_t i = 0; i < n; ++i)
+        r[i] = {base + offsets[i], lengths[i]};
+    return hash_ranges(r, digests, gate);
+}
+
 }  // namespace snappy
 
 using namespace snappy;

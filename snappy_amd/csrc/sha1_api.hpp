@@ -6,6 +6,7 @@
 
 #include "runtime.hpp"
 #include "sha1_launch.hpp"
+#include "transfer.hpp"
 
 namespace snappy {
 
@@ -28,6 +29,11 @@ void finish_sha1_profile(SlotLease &lease);
 int run_sha1_tables(SlotLease &lease, const uint8_t *d_base, const uint64_t *offsets,
                     const uint64_t *lengths, uint64_t n, uint8_t *digests_host,
                     hipStream_t user_stream);
+
+// snappy_sha1_batch for sources that other threads are still filling: the gate is
+// asked before any byte of a source is read.
+int sha1_batch_gated(const uint8_t *base, const uint64_t *offsets, const uint64_t *lengths, uint64_t n,
+                     uint8_t *digests, SourceGate *gate);
 
 // Splits n files into n_shards contiguous groups of near-equal byte count
 // (cuts has n_shards + 1 entries).

@@ -22,7 +22,7 @@ constexpr unsigned kStageThreads = 6;
 // bytes lie.
 hipError_t transfer_direct(Slot &s, const std::vector<Piece> &pieces, uint64_t slice_bytes,
                            uint64_t n_slices, uint8_t *d_base, uint32_t *d_progress,
-                           const uint32_t *slice_numbers)
+                           const uint32_t *slice_numbers, SourceGate *gate)
 {
     hipError_t e = hipSuccess;
     uint64_t next_mark = 1;  // slice whose end has not been marked yet
@@ -32,6 +32,8 @@ hipError_t transfer_direct(Slot &s, const std::vector<Piece> &pieces, uint64_t s
             const uint64_t pos = c.dst + done;
             const uint64_t slice_end = (pos / slice_bytes + 1) * slice_bytes;
             const uint64_t take = std::min<uint64_t>(c.len - done, slice_end - pos);
+            if (gate)
+                gate->wait_for(c.src + done, take);
             e = hipMemcpyAsync(d_base + pos, c.src + done, take, hipMemcpyHostToDevice,
                                s.copy_stream);
             done += take;
@@ -60,7 +62,7 @@ hipError_t transfer_direct(Slot &s, const std::vector<Piece> &pieces, uint64_t s
 // the PCIe link.
 hipError_t transfer_staged(Slot &s, int hip_device, const std::vector<Piece> &pieces,
                            uint64_t slice_bytes, uint64_t n_slices, uint8_t *d_base,
-                           uint32_t *d_progress, const uint32_t *slice_numbers)
+                           uint32_t *d_progress, const uint32_t *slice_numbers, SourceGate *gate)
 {
     struct Segment {
         const uint8_t *src;
@@ -122,8 +124,11 @@ hipError_t transfer_staged(Slot &s, int hip_device, const std::vector<Piece> &pi
                 }
             }
             uint8_t *slot = ring + (k % ring_slots) * slice_bytes;
-            for (size_t q = seg_begin[k]; q < seg_begin[k + 1]; ++q)
+            for (size_t q = seg_begin[k]; q < seg_begin[k + 1]; ++q) {
+                if (gate)
+                    gate->wait_for(segs[q].src, segs[q].len);
                 std::memcpy(slot + (segs[q].dst - k * slice_bytes), segs[q].src, segs[q].len);
+            }
             {
                 std::lock_guard<std::mutex> g(mu);
                 filled[k] = 1;
@@ -327,7 +332,7 @@ int reserve_transfer_ring(Slot &s, uint64_t slice_bytes, uint64_t n_slices)
 
 hipError_t transfer_to_device(Slot &s, int hip_device, const std::vector<Piece> &pieces,
                               uint64_t slice_bytes, uint8_t *d_base, uint32_t *d_progress,
-                              const uint32_t *slice_numbers)
+                              const uint32_t *slice_numbers, SourceGate *gate)
 {
     uint64_t end = 0, bytes = 0;
     for (const Piece &c : pieces) {
@@ -349,9 +354,9 @@ hipError_t transfer_to_device(Slot &s, int hip_device, const std::vector<Piece> 
     const bool stage = may_stage && (d_progress != nullptr || bytes >= (8ull << 20)) &&
                        !sources_are_page_locked(pieces);
     hipError_t e = stage ? transfer_staged(s, hip_device, pieces, slice_bytes, n_slices, d_base,
-                                           d_progress, slice_numbers)
+                                           d_progress, slice_numbers, gate)
                          : transfer_direct(s, pieces, slice_bytes, n_slices, d_base, d_progress,
-                                           slice_numbers);
+                                           slice_numbers, gate);
     if (e == hipSuccess)
         e = hipStreamSynchronize(s.copy_stream);
     return e;

@@ -20,15 +20,23 @@ struct Piece {
 
 constexpr uint64_t kTransferSliceBytes = 32ull << 20;
 
+// Sources that are still being produced (files being read into their buffer by
+// other threads): a transfer asks the gate before it touches source bytes.
+struct SourceGate {
+    virtual ~SourceGate() = default;
+    // Returns once the len bytes at src hold their final content.
+    virtual void wait_for(const uint8_t *src, uint64_t len) = 0;
+};
+
 // Moves the pieces to d_base on the slot's copy stream and waits for them.
 // slice_bytes: granularity (a multiple of 256).  d_progress / slice_numbers (both
 // null, or both set): after slice k of the arena has landed, the 32-bit word
 // *d_progress is set to slice_numbers[k] == k + 1 (slice_numbers: page-locked
 // host memory with one entry per slice).  Small batches of pageable memory are
-// sent with plain copies.
+// sent with plain copies.  gate: asked before source bytes are read.
 hipError_t transfer_to_device(Slot &s, int hip_device, const std::vector<Piece> &pieces,
                               uint64_t slice_bytes, uint8_t *d_base, uint32_t *d_progress,
-                              const uint32_t *slice_numbers);
+                              const uint32_t *slice_numbers, SourceGate *gate = nullptr);
 
 // The other direction: bytes of device memory to a host buffer, after all work on
 // the slot's main stream has finished (the caller has synchronised it).  Ordinary

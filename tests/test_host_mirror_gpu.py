@@ -130,3 +130,36 @@ def test_import_mcdf_errors(snappy, oracle, tmp_path):
     with pytest.raises(snappy.native.SnappyError) as e:
         snappy.import_mcdf(str(tmp_path / "missing.mcdf"), str(tmp_path / "w"))
     assert e.value.code == snappy.native.E_INVALID_ARG
+
+
+def test_store_files_reads_while_hashing(snappy, tmp_path):
+    """A folder large enough for the hash-while-copying path, read by several threads while the
+    transfer is under way; one source cannot be opened and is skipped like a missing one."""
+    import hashlib
+    import os
+    rng = np.random.default_rng(8)
+    paths, want = [], []
+    for i in range(40):
+        size = int(rng.integers(1, 6_000_000)) if i else 24_000_000
+        data = rng.integers(0, 256, size=size, dtype=np.uint8).tobytes()
+        p = tmp_path / f"src{i}.tex"
+        p.write_bytes(data)
+        paths.append(str(p))
+        want.append(hashlib.sha1(data).hexdigest().upper())
+    locked = 7
+    os.chmod(paths[locked], 0)
+    can_open = True
+    try:
+        open(paths[locked], "rb").close()
+    except OSError:
+        can_open = False
+    files_dir = tmp_path / "_files"
+    got = snappy.store_files(paths, str(files_dir))
+    os.chmod(paths[locked], 0o644)
+    for i, (g, w) in enumerate(zip(got, want)):
+        if i == locked and not can_open:
+            assert g is None
+            assert not (files_dir / f"{w}.dat").exists()
+        else:
+            assert g == w, i
+            assert (files_dir / f"{w}.dat").stat().st_size == os.path.getsize(paths[i])
