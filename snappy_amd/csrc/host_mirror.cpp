@@ -41,21 +41,6 @@ namespace snappy {
 
 namespace {
 
-bool read_all_bytes(const std::string &path, std::vector<uint8_t> &out)
-{
-    std::ifstream f(path, std::ios::binary | std::ios::ate);
-    if (!f)
-        return false;
-    const std::streamoff size = f.tellg();
-    if (size < 0)
-        return false;
-    out.resize(static_cast<size_t>(size));
-    f.seekg(0);
-    if (size && !f.read(reinterpret_cast<char *>(out.data()), size))
-        return false;
-    return true;
-}
-
 bool write_all_bytes(const std::string &path, const uint8_t *data, size_t n)
 {
     std::ofstream f(path, std::ios::binary | std::ios::trunc);
@@ -246,13 +231,43 @@ public:
                 return SNAPPY_OK;
             }
         }
+        own_cap_ = bytes;
         return snappy_host_alloc(bytes, &ptr_);
+    }
+    // Makes room for `bytes`, keeping the first `keep` bytes.
+    int grow(uint64_t bytes, uint64_t keep)
+    {
+        if (shared_) {
+            std::lock_guard<std::mutex> lk(g_file_arena.mu);
+            if (g_file_arena.cap >= bytes)
+                return SNAPPY_OK;
+        } else if (own_cap_ >= bytes) {
+            return SNAPPY_OK;
+        }
+        void *bigger = nullptr;
+        const uint64_t want = bytes + bytes / 4;
+        int st = snappy_host_alloc(want, &bigger);
+        if (st != SNAPPY_OK)
+            return st;
+        if (keep)
+            std::memcpy(bigger, ptr_, static_cast<size_t>(keep));
+        (void)snappy_host_free(ptr_);
+        ptr_ = bigger;
+        if (shared_) {
+            std::lock_guard<std::mutex> lk(g_file_arena.mu);
+            g_file_arena.ptr = bigger;
+            g_file_arena.cap = want;
+        } else {
+            own_cap_ = want;
+        }
+        return SNAPPY_OK;
     }
     uint8_t *data() const { return static_cast<uint8_t *>(ptr_); }
 
 private:
     void *ptr_ = nullptr;
     bool shared_ = false;
+    uint64_t own_cap_ = 0;
 };
 
 // Runs fn(k) for k in [0, n) on up to kIoThreads threads (file reads and writes
@@ -300,6 +315,33 @@ bool read_exact(const char *path, uint8_t *dst, uint64_t size)
     const bool grew = done == size && ::pread(fd, &probe, 1, static_cast<off_t>(size)) == 1;
     ::close(fd);
     return done == size && !grew;
+}
+
+// The same with several threads, each reading a range of the file: one thread does
+// not reach the page cache's bandwidth, let alone a fast disk's.
+bool read_exact_parallel(const char *path, uint8_t *dst, uint64_t size)
+{
+    constexpr uint64_t kPart = 8ull << 20;
+    if (size <= 2 * kPart)
+        return read_exact(path, dst, size);
+    const int fd = ::open(path, O_RDONLY | O_CLOEXEC);
+    if (fd < 0)
+        return false;
+    std::atomic<bool> ok{true};
+    parallel_for((size + kPart - 1) / kPart, [&](uint64_t k) {
+        uint64_t done = k * kPart;
+        const uint64_t end = std::min<uint64_t>(size, done + kPart);
+        while (done < end) {
+            const ssize_t r = ::pread(fd, dst + done, static_cast<size_t>(end - done), static_cast<off_t>(done));
+            if (r <= 0) {
+                ok.store(false);
+                return;
+            }
+            done += static_cast<uint64_t>(r);
+        }
+    });
+    ::close(fd);
+    return ok.load();
 }
 
 }  // namespace
@@ -505,26 +547,39 @@ extern "C" int snappy_mcdf_import_to_dir(const char *mcdf_path, const char *work
 {
     if (!mcdf_path || !working_dir)
         return SNAPPY_E_INVALID_ARG;
-    std::vector<uint8_t> stream;
-    if (!read_all_bytes(mcdf_path, stream)) {
+    // The file and the decoded payload share one page-locked arena: both cross PCIe by
+    // direct DMA, and neither costs a fresh allocation's page faults.
+    std::error_code size_ec;
+    const uint64_t stream_len = static_cast<uint64_t>(fs::file_size(mcdf_path, size_ec));
+    if (size_ec) {
+        set_error_detail(std::string("cannot read ") + mcdf_path);
+        return SNAPPY_E_INVALID_ARG;
+    }
+    const uint64_t payload_at = (stream_len + 511) & ~uint64_t(255);
+    ArenaLease arena;
+    int st = arena.acquire(payload_at + 2 * stream_len + 256);
+    if (st != SNAPPY_OK)
+        return st;
+    if (!read_exact_parallel(mcdf_path, arena.data(), stream_len)) {
         set_error_detail(std::string("cannot read ") + mcdf_path);
         return SNAPPY_E_INVALID_ARG;
     }
     // lz4Stream.CopyTo(memoryStream) + header + ExtractAndHashMapFiles, fused on the GPU.
     uint64_t decoded = 0;
-    int st = snappy_lz4net_decoded_size(stream.data(), stream.size(), &decoded);
+    st = snappy_lz4net_decoded_size(arena.data(), stream_len, &decoded);
     if (st != SNAPPY_OK)
         decoded = 0;  // the fused call reports stream errors in stream order
-    std::vector<uint8_t> payload(static_cast<size_t>(decoded));
+    if ((st = arena.grow(payload_at + decoded + 256, stream_len)) != SNAPPY_OK)
+        return st;
+    const uint8_t *stream = arena.data();
+    uint8_t *payload = arena.data() + payload_at;
     uint64_t n_files = 0, body = 0, payload_len = 0, cap = 1024;
     std::vector<uint8_t> digests, statuses;
     for (;;) {
         digests.assign(cap * 20, 0);
         statuses.assign(cap, 0);
-        st = snappy_mcdf_decode_and_hash(stream.data(), stream.size(), digests.data(),
-                                         statuses.data(), cap, &n_files, &body,
-                                         payload.empty() ? nullptr : payload.data(), payload.size(),
-                                         &payload_len);
+        st = snappy_mcdf_decode_and_hash(stream, stream_len, digests.data(), statuses.data(), cap, &n_files,
+                                         &body, decoded ? payload : nullptr, decoded, &payload_len);
         if (st == SNAPPY_E_CAPACITY && n_files > cap) {
             cap = n_files;
             continue;
@@ -534,7 +589,7 @@ extern "C" int snappy_mcdf_import_to_dir(const char *mcdf_path, const char *work
     if (st != SNAPPY_OK)
         return st;
     McdfHeaderInfo info;
-    st = parse_mcdf_header(payload.data(), payload_len, info);
+    st = parse_mcdf_header(payload, payload_len, info);
     if (st != SNAPPY_OK)
         return st;
 
@@ -583,7 +638,7 @@ extern "C" int snappy_mcdf_import_to_dir(const char *mcdf_path, const char *work
         const std::string target = (files / (hashes[i] + ".dat")).string();
         std::error_code e2;
         if (!fs::exists(target, e2) &&
-            !write_all_bytes(target, payload.data() + slices[i].offset, slices[i].length)) {
+            !write_all_bytes(target, payload + slices[i].offset, slices[i].length)) {
             write_failed.store(true);
             std::lock_guard<std::mutex> lk(fail_mu);
             failed_target = target;
