@@ -326,6 +326,34 @@ plan_scatter(const uint64_t *__restrict__ offsets, const uint64_t *__restrict__ 
     }
 }
 
+// A batch of one message needs no sorting and no search: one thread writes the
+// task and a header that gives the message the fastest chain (or the forced
+// path).  A single GetHash call is three kernel launches shorter for it.
+__global__ void plan_single(const uint64_t *__restrict__ offsets, const uint64_t *__restrict__ lengths,
+                            const uint32_t *__restrict__ epochs, Sha1PlanState *__restrict__ st,
+                            Sha1Task *__restrict__ tasks, Sha1CostModel m)
+{
+    if (threadIdx.x != 0)
+        return;
+    const uint64_t blocks = padded_blocks(lengths[0]);
+    const int path = m.forced_path >= 0 ? m.forced_path : 0;
+    for (int q = 0; q < kSha1Paths; ++q) {
+        st->path_end[q] = q >= path ? 1u : 0u;
+        st->chain_ns[q] = static_cast<float>(m.chain_ns[q]);
+        st->queue[q].next = 0;
+    }
+    st->total_blocks = blocks;
+    st->max_blocks = blocks;
+    st->planned_ns = m.forced_path >= 0 ? 0.0 : static_cast<double>(blocks) * m.chain_ns[0];
+    st->waves_per_simd = 1;
+    Sha1Task t;
+    t.offset = offsets[0];
+    t.len = lengths[0];
+    t.out_index = 0;
+    t.ready_epoch = epochs ? epochs[0] : 0u;
+    tasks[0] = t;
+}
+
 }  // namespace
 
 hipError_t launch_sha1_plan(const uint64_t *d_offsets, const uint64_t *d_lengths,
@@ -334,6 +362,11 @@ hipError_t launch_sha1_plan(const uint64_t *d_offsets, const uint64_t *d_lengths
 {
     if (n == 0)
         return hipSuccess;
+    if (n == 1) {
+        hipLaunchKernelGGL(plan_single, dim3(1), dim3(64), 0, stream, d_offsets, d_lengths, d_epochs,
+                           d_state, d_tasks, model);
+        return hipGetLastError();
+    }
     hipError_t e = hipMemsetAsync(d_state, 0, sizeof(Sha1PlanState), stream);
     if (e != hipSuccess)
         return e;

@@ -360,3 +360,15 @@ def test_held_up_transfer_still_gives_right_digests(snappy, oracle):
     os.environ.pop("SNAPPY_TEST_TRANSFER_DELAY_MS")
     os.environ.pop("SNAPPY_ARRIVAL_MAX_POLLS")
     assert np.array_equal(snappy.sha1_batch(base, offsets, sizes), oracle.sha1_batch_np(base, offsets, sizes))
+
+
+def test_single_message_calls_on_every_path(snappy):
+    """A batch of one message skips the sorting kernels: one GetHash call per length, on the
+    planner's path and on every forced one."""
+    import hashlib
+    for path in ALL_PATHS + (None,):
+        force_path(path)
+        for n in (0, 1, 55, 56, 63, 64, 65, 119, 120, 1000, 4096, 100_003, 1_500_000):
+            data = H.splitmix_bytes(n, 900 + n)
+            assert snappy.get_hash(data) == hashlib.sha1(data).hexdigest().upper(), (path, n)
+    force_path(None)
