@@ -131,7 +131,35 @@ lz4_encode_kernel(const uint8_t *__restrict__ base_in, uint8_t *__restrict__ bas
         out_sizes[blockIdx.x] = o;
 }
 
+// Source and destination start at any byte; dword accesses at any byte address
+// are fine on this hardware, so the copy runs in dwords with a byte tail.
+__global__ void __launch_bounds__(256)
+lz4_pack_kernel(uint8_t *__restrict__ base, const Lz4PackItem *__restrict__ items)
+{
+    const Lz4PackItem it = items[blockIdx.x];
+    const uint8_t *src = base + it.src;
+    uint8_t *dst = base + it.dst;
+    const uint64_t words = it.len >> 2;
+    for (uint64_t i = threadIdx.x; i < words; i += 256) {
+        uint32_t w;
+        __builtin_memcpy(&w, src + 4 * i, 4);
+        __builtin_memcpy(dst + 4 * i, &w, 4);
+    }
+    const uint64_t tail = words << 2;
+    if (threadIdx.x < (it.len & 3u))
+        dst[tail + threadIdx.x] = src[tail + threadIdx.x];
+}
+
 }  // namespace
+
+hipError_t launch_lz4_pack(uint8_t *d_base, const Lz4PackItem *d_items, uint32_t n_items,
+                           hipStream_t stream)
+{
+    if (n_items == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(lz4_pack_kernel, dim3(n_items), dim3(256), 0, stream, d_base, d_items);
+    return hipGetLastError();
+}
 
 hipError_t launch_lz4_encode(const uint8_t *d_in, uint8_t *d_out, const Lz4EncChunk *d_chunks,
                              uint32_t n_chunks, uint32_t *d_out_sizes, hipStream_t stream)

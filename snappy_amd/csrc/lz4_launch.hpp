@@ -39,4 +39,17 @@ struct Lz4EncChunk {
 hipError_t launch_lz4_encode(const uint8_t *d_in, uint8_t *d_out, const Lz4EncChunk *d_chunks,
                              uint32_t n_chunks, uint32_t *d_out_sizes, hipStream_t stream);
 
+// One piece of the finished stream: len bytes at d_base + src go to d_base + dst.
+struct Lz4PackItem {
+    uint64_t src;
+    uint64_t dst;
+    uint64_t len;
+};
+
+// Gathers the chunks' payloads (compressed blocks, or the input bytes of chunks
+// that did not shrink) at their places in the stream, one workgroup per item, so
+// that the stream leaves the device in one transfer.  Ranges do not overlap.
+hipError_t launch_lz4_pack(uint8_t *d_base, const Lz4PackItem *d_items, uint32_t n_items,
+                           hipStream_t stream);
+
 }  // namespace snappy

@@ -314,9 +314,11 @@ extern "C" int snappy_lz4net_encode(const uint8_t *in, uint64_t in_len, uint32_t
     Slot &s = *lease.slot;
     profile_reset();
 
-    // Arena: [input][one worst-case output area per chunk].
+    // Arena: [input][one worst-case output area per chunk][the finished stream].
     const uint64_t area = (bs + bs / 255 + 16 + 15) & ~uint64_t(15);
     const uint64_t in_area = (in_len + 15) & ~uint64_t(15);
+    const uint64_t stream_at = in_area + n_chunks * area;
+    const uint64_t stream_room = in_len + 16 * n_chunks + 256;  // headers are at most 11 bytes per chunk
     std::vector<Lz4EncChunk> chunks(n_chunks);
     for (uint64_t k = 0; k < n_chunks; ++k) {
         chunks[k].in_off = k * bs;
@@ -324,8 +326,9 @@ extern "C" int snappy_lz4net_encode(const uint8_t *in, uint64_t in_len, uint32_t
         chunks[k].in_len = static_cast<uint32_t>(std::min<uint64_t>(bs, in_len - k * bs));
         chunks[k].reserved = 0;
     }
-    if ((st = s.d_data.ensure(in_area + n_chunks * area)) != SNAPPY_OK) return st;
+    if ((st = s.d_data.ensure(stream_at + stream_room)) != SNAPPY_OK) return st;
     if ((st = s.d_tasks.ensure(n_chunks * sizeof(Lz4EncChunk))) != SNAPPY_OK) return st;
+    if ((st = s.d_tables.ensure(n_chunks * sizeof(Lz4PackItem))) != SNAPPY_OK) return st;
     if ((st = s.d_out.ensure(n_chunks * sizeof(uint32_t))) != SNAPPY_OK) return st;
     uint8_t *d_base = static_cast<uint8_t *>(s.d_data.ptr);
     Lz4EncChunk *d_chunks = static_cast<Lz4EncChunk *>(s.d_tasks.ptr);
@@ -366,21 +369,32 @@ extern "C" int snappy_lz4net_encode(const uint8_t *in, uint64_t in_len, uint32_t
     *out_len = need;
     if (need > out_cap)
         return SNAPPY_E_CAPACITY;
+    // The payloads are gathered at their places in the stream on the device, the
+    // stream comes back in one transfer, and the headers are written into the gaps.
+    std::vector<Lz4PackItem> items(n_chunks);
     uint64_t o = 0;
+    for (uint64_t k = 0; k < n_chunks; ++k) {
+        const uint64_t n = chunks[k].in_len, c = sizes[k];
+        const bool compressed = c < n;
+        o += 1 + varint_size(n) + (compressed ? varint_size(c) : 0);
+        items[k] = {compressed ? chunks[k].out_off : chunks[k].in_off, stream_at + o, compressed ? c : n};
+        o += items[k].len;
+    }
+    Lz4PackItem *d_items = static_cast<Lz4PackItem *>(s.d_tables.ptr);
+    SNAPPY_HIP_TRY(hipMemcpyAsync(d_items, items.data(), n_chunks * sizeof(Lz4PackItem),
+                                  hipMemcpyHostToDevice, s.stream));
+    SNAPPY_HIP_TRY(launch_lz4_pack(d_base, d_items, static_cast<uint32_t>(n_chunks), s.stream));
+    SNAPPY_HIP_TRY(hipStreamSynchronize(s.stream));
+    SNAPPY_HIP_TRY(transfer_to_host(s, lease.dev->hip_device, d_base + stream_at, out, need));
+    o = 0;
     for (uint64_t k = 0; k < n_chunks; ++k) {
         const uint64_t n = chunks[k].in_len, c = sizes[k];
         const bool compressed = c < n;
         o = put_varint(out, o, compressed ? 1u : 0u);
         o = put_varint(out, o, n);
-        if (compressed) {
+        if (compressed)
             o = put_varint(out, o, c);
-            SNAPPY_HIP_TRY(hipMemcpyAsync(out + o, d_base + chunks[k].out_off, c,
-                                          hipMemcpyDeviceToHost, s.stream));
-            o += c;
-        } else {
-            std::memcpy(out + o, in + chunks[k].in_off, n);
-            o += n;
-        }
+        o += items[k].len;
     }
     SNAPPY_HIP_TRY(hipStreamSynchronize(s.stream));
     return SNAPPY_OK;
