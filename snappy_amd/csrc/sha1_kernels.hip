@@ -244,16 +244,19 @@ __device__ __forceinline__ HopResult lanes_once(const uint8_t *__restrict__ base
 
     uint32_t w[16];
     for (uint64_t blk = 0; __ballot(blk < n_full) != 0; blk += 2) {
+        // Both blocks of the next pair are asked for at once: the two halves of a
+        // 128-byte line then arrive together instead of a block's time apart.
+        uint32_t w2[16];
         raw_block_to_be(even, shift, w);
+        raw_block_to_be(odd, shift, w2);
         if (blk + 2 < n_full)
             load_block_raw(msg + ((blk + 2) << 6), shift, even);
+        if (blk + 3 < n_full)
+            load_block_raw(msg + ((blk + 3) << 6), shift, odd);
         compress_if(blk < n_full, h, w);
         if (__ballot(blk + 1 < n_full) == 0)
             break;
-        raw_block_to_be(odd, shift, w);
-        if (blk + 3 < n_full)
-            load_block_raw(msg + ((blk + 3) << 6), shift, odd);
-        compress_if(blk + 1 < n_full, h, w);
+        compress_if(blk + 1 < n_full, h, w2);
     }
     const bool closed = load_tail_block_be(msg + (n_full << 6), rem, len, w);
     compress_if(have, h, w);
