@@ -127,6 +127,22 @@ int snappy_sha1_batch_resident(int device, const void *d_base, const uint64_t *d
                                const uint64_t *d_lengths, uint64_t n, uint8_t *d_digests,
                                void *stream);
 
+/* snappy_sha1_batch_resident for callers that cannot allocate device memory:
+ * code under HIP graph capture, tight serving loops, harnesses that forbid
+ * hipMalloc.  Same arguments, same digests; no counterpart in the reference.
+ * The planner's header and the sorted task list live in a fixed array inside
+ * the library (24 MiB + 16 KiB per GPU, held until the process ends) instead of
+ * pooled buffers, so the call issues no hipMalloc / hipFree / stream or event
+ * creation of its own.  Limits: at most SNAPPY_NOALLOC_MAX_FILES files per call
+ * (SNAPPY_E_CAPACITY beyond); snappy_init must have run (the call does not
+ * initialise the library); `stream` NULL means the device's default stream.
+ * All calls on one GPU share the array: the library makes overlapping calls
+ * take turns, and nothing in it survives from one call to the next. */
+#define SNAPPY_NOALLOC_MAX_FILES (1u << 20)
+int snappy_sha1_batch_resident_noalloc(int device, const void *d_base,
+                                       const uint64_t *d_offsets, const uint64_t *d_lengths,
+                                       uint64_t n, uint8_t *d_digests, void *stream);
+
 /* How snappy_sha1_batch / snappy_sha1_files split a batch over devices: files
  * are independent, so shard k is the contiguous group cuts[k] .. cuts[k+1] of
  * near-equal byte count (cuts has n_shards + 1 entries).  Host only; exposed so

@@ -18,6 +18,7 @@ LIB = os.path.join(HERE, "libsnappyhash.so")
 SOURCES = [
     "sha1_kernels.hip",
     "sha1_plan.hip",
+    "sha1_noalloc.hip",
     "lz4_kernels.hip", "lz4_encode.hip",
     "runtime.cpp", "transfer.cpp",
     "sha1_api.cpp",

@@ -1,5 +1,6 @@
 // Device contexts, slot pool and lifecycle entry points of libsnappyhash.
 #include "runtime.hpp"
+#include "sha1_api.hpp"
 
 #include <atomic>
 #include <cstdlib>
@@ -107,6 +108,13 @@ int init_locked(int n_devices)
         hipDeviceProp_t prop;
         SNAPPY_HIP_TRY(hipGetDeviceProperties(&prop, d));
         ctx->n_cu = prop.multiProcessorCount;
+        SNAPPY_HIP_TRY(hipSetDevice(d));
+        int st = noalloc_setup_device(d);
+        if (st != SNAPPY_OK) {
+            g_devices.clear();
+            g_init_status = st;
+            return st;
+        }
         g_devices.push_back(std::move(ctx));
     }
     g_initialized = true;
@@ -172,6 +180,14 @@ int pick_device()
 {
     const int n = device_count();
     return n > 0 ? static_cast<int>(g_round_robin.fetch_add(1) % static_cast<unsigned>(n)) : 0;
+}
+
+DeviceCtx *bound_device(int device)
+{
+    std::lock_guard<std::mutex> lk(g_init_mu);
+    if (!g_initialized || device < 0 || static_cast<size_t>(device) >= g_devices.size())
+        return nullptr;
+    return g_devices[static_cast<size_t>(device)].get();
 }
 
 bool profiling_enabled() { return g_profile.load(std::memory_order_relaxed) != 0; }

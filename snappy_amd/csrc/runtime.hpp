@@ -83,6 +83,9 @@ public:
 int ensure_initialized();          // SNAPPY_OK or SNAPPY_E_NO_DEVICE / SNAPPY_E_HIP
 int device_count();                // after ensure_initialized
 int pick_device();                 // round-robin choice for single-buffer calls
+// The bound device `device`, or null when the library is not initialised or the
+// index is out of range.  Initialises nothing and allocates nothing.
+DeviceCtx *bound_device(int device);
 bool profiling_enabled();
 void profile_reset();
 void profile_store(int kernel, float ms);

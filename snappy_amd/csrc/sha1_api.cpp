@@ -46,23 +46,8 @@ long env_long(const char *name, long fallback)
 
 }  // namespace
 
-int enqueue_sha1_resident(SlotLease &lease, const uint8_t *d_base, const uint64_t *d_offsets,
-                          const uint64_t *d_lengths, uint64_t n, uint8_t *d_digests,
-                          hipStream_t stream, const uint32_t *d_epochs, Sha1Arrival *d_arrival)
+Sha1CostModel sha1_cost_model(uint32_t n_simd, bool waits_for_transfer)
 {
-    Slot &s = *lease.slot;
-    if (n == 0)
-        return SNAPPY_OK;
-    if (n >= 0xFFFFFFF0ull)
-        return SNAPPY_E_INVALID_ARG;
-    int st;
-    if ((st = s.d_tasks.ensure(n * sizeof(Sha1Task))) != SNAPPY_OK) return st;
-    if ((st = s.d_misc.ensure(sizeof(Sha1PlanState))) != SNAPPY_OK) return st;
-    Sha1PlanState *d_state = static_cast<Sha1PlanState *>(s.d_misc.ptr);
-    Sha1Task *d_tasks = static_cast<Sha1Task *>(s.d_tasks.ptr);
-    const uint32_t n32 = static_cast<uint32_t>(n);
-    const uint32_t n_simd = 4u * static_cast<uint32_t>(lease.dev->n_cu);
-
     Sha1CostModel model;
     for (int k = 0; k < kSha1Paths; ++k) {
         model.chain_ns[k] = kChainNs[k];
@@ -83,8 +68,29 @@ int enqueue_sha1_resident(SlotLease &lease, const uint8_t *d_base, const uint64_
     // Waves that wait for a transfer must leave registers free on every SIMD: small
     // copies are carried out by copy kernels, which would otherwise never be placed
     // (two of these waves fill a SIMD's register file).
-    if (d_arrival != nullptr)
+    if (waits_for_transfer)
         model.forced_waves = 1;
+    return model;
+}
+
+int enqueue_sha1_resident(SlotLease &lease, const uint8_t *d_base, const uint64_t *d_offsets,
+                          const uint64_t *d_lengths, uint64_t n, uint8_t *d_digests,
+                          hipStream_t stream, const uint32_t *d_epochs, Sha1Arrival *d_arrival)
+{
+    Slot &s = *lease.slot;
+    if (n == 0)
+        return SNAPPY_OK;
+    if (n >= 0xFFFFFFF0ull)
+        return SNAPPY_E_INVALID_ARG;
+    int st;
+    if ((st = s.d_tasks.ensure(n * sizeof(Sha1Task))) != SNAPPY_OK) return st;
+    if ((st = s.d_misc.ensure(sizeof(Sha1PlanState))) != SNAPPY_OK) return st;
+    Sha1PlanState *d_state = static_cast<Sha1PlanState *>(s.d_misc.ptr);
+    Sha1Task *d_tasks = static_cast<Sha1Task *>(s.d_tasks.ptr);
+    const uint32_t n32 = static_cast<uint32_t>(n);
+    const uint32_t n_simd = 4u * static_cast<uint32_t>(lease.dev->n_cu);
+
+    const Sha1CostModel model = sha1_cost_model(n_simd, d_arrival != nullptr);
 
     const bool prof = profiling_enabled();
     if (prof)

@@ -10,6 +10,16 @@
 
 namespace snappy {
 
+// The planner's measured cost table for a device with n_simd SIMDs, with the
+// tuning variables applied.  waits_for_transfer: the kernel will poll an arrival
+// counter, so only one wave per SIMD may stay.
+Sha1CostModel sha1_cost_model(uint32_t n_simd, bool waits_for_transfer);
+
+// Looks up each bound device's copy of the file-scope planning area used by
+// snappy_sha1_batch_resident_noalloc (sha1_noalloc.hip).  Called by the
+// library's initialisation with hip_device current.
+int noalloc_setup_device(int hip_device);
+
 // Plans and launches the SHA-1 kernels for n messages whose (offset, length)
 // tables and data are all in device memory; digests (20 bytes per message, in
 // the caller's message order) are written to d_digests.  Enqueues only.

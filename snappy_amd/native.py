@@ -50,6 +50,7 @@ SYMBOLS = [
     ("snappy_digests_to_hex", _i, [_vp, _u64, _vp]),
     ("snappy_sha1_batch_device", _i, [_i, _vp, _vp, _vp, _u64, _vp, _vp]),
     ("snappy_sha1_batch_resident", _i, [_i, _vp, _vp, _vp, _u64, _vp, _vp]),
+    ("snappy_sha1_batch_resident_noalloc", _i, [_i, _vp, _vp, _vp, _u64, _vp, _vp]),
     ("snappy_plan_shards", _i, [_vp, _u64, ctypes.c_uint32, _vp]),
     ("snappy_lz4net_decoded_size", _i, [_vp, _u64, _u64p]),
     ("snappy_lz4net_decode", _i, [_vp, _u64, _vp, _u64, _u64p]),
