@@ -47,6 +47,11 @@ extern "C" {
 #define SNAPPY_E_MCDF_VERSION    (-21) /* version byte != 1                                       */
 #define SNAPPY_E_MCDF_TRUNCATED  (-22) /* payload ends inside the header                          */
 #define SNAPPY_E_MCDF_JSON       (-23) /* header JSON does not parse into McdfData                */
+#define SNAPPY_E_MCDF_BASE64     (-24) /* CustomizePlusData is not Base64 (FormatException,       */
+                                       /* Convert.FromBase64String at McdfManager.cs:136)        */
+/* UpdateSnapshot: an existing snapshot.json / *_history.json does not deserialize
+ * (JsonConvert.DeserializeObject throws, Snappy/Core/SnapshotManager.cs:434-450) */
+#define SNAPPY_E_SNAPSHOT_JSON   (-30)
 
 /* Per-file status written by the MCDF entry points (McdfManager.cs:36-63). */
 #define SNAPPY_FILE_HASHED             0
@@ -143,12 +148,29 @@ int snappy_sha1_batch_resident_noalloc(int device, const void *d_base,
                                        const uint64_t *d_offsets, const uint64_t *d_lengths,
                                        uint64_t n, uint8_t *d_digests, void *stream);
 
-/* How snappy_sha1_batch / snappy_sha1_files split a batch over devices: files
- * are independent, so shard k is the contiguous group cuts[k] .. cuts[k+1] of
- * near-equal byte count (cuts has n_shards + 1 entries).  Host only; exposed so
- * that a caller running one process per GPU can shard a file list the same way.
- * No counterpart in the reference (its loops are sequential). */
+/* How snappy_sha1_batch / snappy_sha1_files deal a batch out to the devices
+ * (files are independent, nothing is exchanged): longest processing time first
+ * by padded 64-byte blocks, (len + 8) / 64 + 1 per file.  Files of at least 1/64
+ * of a device's average share are sorted by size and each goes to the device
+ * with the fewest blocks so far; the small files that remain fill the devices up
+ * to the average in caller order, as contiguous runs.  shard_of[i] receives the
+ * shard of file i; shard_blocks (may be NULL) the n_shards block totals.  Host
+ * only; exposed so that a caller running one process per GPU shards a file list
+ * the same way.  No counterpart in the reference (its loop is sequential,
+ * Snappy/Core/SnapshotManager.cs:312-324). */
+int snappy_plan_shards_lpt(const uint64_t *lengths, uint64_t n, uint32_t n_shards,
+                           uint32_t *shard_of, uint64_t *shard_blocks);
+
+/* The simpler split into contiguous groups of near-equal byte count: shard k is
+ * cuts[k] .. cuts[k+1] (cuts has n_shards + 1 entries).  For callers whose
+ * shards must be ranges of the list.  Host only; no counterpart in the reference. */
 int snappy_plan_shards(const uint64_t *lengths, uint64_t n, uint32_t n_shards, uint64_t *cuts);
+
+/* Diagnostic: what the host-pointer entry points have given device `device`
+ * since it was bound -- files (archives for the MCDF entry points) and their
+ * bytes, counted where the device's slot is held.  Shows where a sharded call
+ * actually ran.  No counterpart in the reference. */
+int snappy_device_work(int device, uint64_t *units, uint64_t *bytes);
 
 /* ----------------------------------------------------- lz4net stream + MCDF */
 
@@ -193,8 +215,12 @@ int snappy_mcdf_decode_and_hash(const uint8_t *in, uint64_t in_len,
  * only a few hundred 1 MiB chunks.  digests/statuses hold the Files entries of
  * archive 0, then archive 1, ... (n_files[a] entries each; n_files_cap is their
  * total capacity).  archive_status[a] is that archive's SNAPPY_* status; an
- * archive that failed contributes no entries and does not disturb the others.
- * body_offsets and payload_lens may be NULL. */
+ * archive that failed contributes no entries and does not disturb the others
+ * (one whose declared size cannot be allocated next to the rest gets
+ * SNAPPY_E_NOMEM).  With several devices the archives are sharded by archive,
+ * largest decoded size first onto the least loaded device, so that each payload
+ * is decoded and hashed in one device's HBM.  body_offsets and payload_lens may
+ * be NULL. */
 int snappy_mcdf_decode_and_hash_batch(uint64_t n_archives, const uint8_t *const *ins,
                                       const uint64_t *in_lens, uint8_t *digests,
                                       uint8_t *statuses, uint64_t n_files_cap,
@@ -213,13 +239,50 @@ int snappy_mcdf_decode_and_hash_batch(uint64_t n_archives, const uint8_t *const 
 int snappy_store_files(const char *const *paths, uint64_t n, const char *files_dir,
                        char *hex, uint8_t *status);
 
+/* SnapshotManager.UpdateSnapshot for the local player without the game and the
+ * plugin IPC: what a press of "save snapshot" leaves on disk.
+ * Inputs are what Penumbra / Glamourer / Customize+ hand the plugin
+ * (Snappy/Core/SnapshotManager.cs:295-307): n_files resolved file paths, file i
+ * with paths_per_file[i] game paths (all files' game paths one after the other
+ * in game_paths), and the three state strings (NULL = empty).
+ *   - every resolved path that names an existing file is read and hashed (one GPU
+ *     batch); resolvedPaths[hash] = path, last writer wins;
+ *     newFileReplacements[gamePath] = hash, case-sensitive (:312-324);
+ *   - snapshot_dir and snapshot_dir/_files are created; an existing
+ *     snapshot.json, glamourer_history.json and customize_history.json are read
+ *     back (:424-451; SNAPPY_E_SNAPSHOT_JSON when one does not parse);
+ *   - the new pairs are merged into FileReplacements (OrdinalIgnoreCase keys:
+ *     the first spelling stays, the last hash wins) and _files/<HASH>.dat is
+ *     written unless present (:453-475).  The bytes written are the ones that
+ *     were hashed, so no source is read twice and a hash shared by many game
+ *     paths is stored once;
+ *   - ManipulationString is replaced, a Glamourer / Customize+ history entry is
+ *     appended when the value differs from the last entry's (:477-511; the
+ *     Customize+ data is stored as Base64 of its UTF-8 bytes, its importable
+ *     template left empty), LastUpdate is set, and the three files are written
+ *     as JsonConvert does with Formatting.Indented (:672-695).
+ * source_actor names a new snapshot (SnapshotInfo.SourceActor); an existing one
+ * keeps its own.  hex (41*n_files bytes) and status (n_files bytes) may be NULL;
+ * otherwise as snappy_store_files. */
+int snappy_update_snapshot(const char *snapshot_dir, const char *source_actor,
+                           const char *const *resolved_paths, const char *const *game_paths,
+                           const uint32_t *paths_per_file, uint64_t n_files,
+                           const char *glamourer, const char *customize,
+                           const char *manipulation, char *hex, uint8_t *status);
+
 /* McdfManager.ImportMcdf without UI and plugin IPC (McdfManager.cs:68-156):
  * reads the archive, decodes and hashes it on the GPU, and writes the snapshot
  * folder working_dir/<Description or MCDF_Import_yyyyMMddHHmmss> (replaced when
  * it exists): _files/<HASH>.dat for every file body, snapshot.json (Snappy/
  * Models/SnapshotInfo.cs:6-14), glamourer_history.json, customize_history.json
  * (SnapshotManager.cs:672-695; the importable Customize+ template is left
- * empty).  snapshot_dir_out (may be NULL) receives the folder's path. */
+ * empty).  snapshot_dir_out (may be NULL) receives the folder's path.
+ * Deliberately stricter than the reference in one respect: the Description
+ * comes out of a file made by someone else and names the folder that is
+ * deleted and recreated, so one that is not a single path component ("..",
+ * ".", absolute, containing '/' or '\\') is refused with SNAPPY_E_INVALID_ARG
+ * before the file system is touched (the reference passes it to Path.Combine
+ * and Directory.Delete as it is, McdfManager.cs:93-107). */
 int snappy_mcdf_import_to_dir(const char *mcdf_path, const char *working_dir,
                               char *snapshot_dir_out, uint64_t out_cap);
 

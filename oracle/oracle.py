@@ -333,3 +333,81 @@ def build_mcdf_payload(description: str, files, extra: dict | None = None) -> by
         if body:
             out += body
     return bytes(out)
+
+
+# ------------------------------------------------------------------ snapshot folder
+
+def _ignore_case_set(d: dict, key: str, value):
+    """Indexer set of Dictionary<string,string>(OrdinalIgnoreCase) kept as {folded: [key, value]}."""
+    k = _ordinal_upper(key)
+    if k in d:
+        d[k][1] = value
+    else:
+        d[k] = [key, value]
+
+
+def update_snapshot(snapshot_dir: str, source_actor: str, replacements, glamourer: str = "",
+                    customize: str = "", manipulation: str = "") -> str:
+    """UpdateSnapshot for the local player (Snappy/Core/SnapshotManager.cs:292-332, 408-527) on the
+    file system, sequential like the reference.  replacements = [(resolved_path, [game paths])].
+    Time stamps are written as fixed markers; CustomizeTemplate is left empty."""
+    import base64
+
+    new_replacements, resolved_paths = {}, {}        # ordinary (case-sensitive) dictionaries
+    for resolved, game_paths in replacements:        # :312-324
+        if not os.path.isfile(resolved):
+            continue
+        with open(resolved, "rb") as f:
+            h = get_hash(f.read())
+        resolved_paths[h] = resolved
+        for g in game_paths:
+            new_replacements[g] = h
+    files_dir = os.path.join(snapshot_dir, "_files")
+    os.makedirs(files_dir, exist_ok=True)            # :424-425
+    info_path = os.path.join(snapshot_dir, "snapshot.json")
+    glam_path = os.path.join(snapshot_dir, "glamourer_history.json")
+    cust_path = os.path.join(snapshot_dir, "customize_history.json")
+    info = {"FormatVersion": 1, "SourceActor": source_actor, "LastUpdate": "", "FileReplacements": {},
+            "ManipulationString": ""}
+    folded = {}
+    if os.path.exists(info_path):                    # :431-435
+        old = json.load(open(info_path, encoding="utf-8-sig"))
+        info["FormatVersion"] = _ci_get(old, "FormatVersion", 1)
+        info["SourceActor"] = _ci_get(old, "SourceActor", "") or ""
+        for k, v in (_ci_get(old, "FileReplacements", {}) or {}).items():
+            _ignore_case_set(folded, k, v)
+    glam = {"Entries": []}
+    if os.path.exists(glam_path):
+        for e in (_ci_get(json.load(open(glam_path, encoding="utf-8-sig")), "Entries", []) or []):
+            glam["Entries"].append({k: _ci_get(e, k, "") or "" for k in ("Timestamp", "Description", "GlamourerString")})
+    cust = {"Entries": []}
+    if os.path.exists(cust_path):
+        for e in (_ci_get(json.load(open(cust_path, encoding="utf-8-sig")), "Entries", []) or []):
+            cust["Entries"].append({k: _ci_get(e, k, "") or ""
+                                    for k in ("Timestamp", "Description", "CustomizeData", "CustomizeTemplate")})
+    for game_path, h in new_replacements.items():    # :453-475
+        _ignore_case_set(folded, game_path, h)
+        target = os.path.join(files_dir, h + ".dat")
+        if not os.path.exists(target):
+            source = resolved_paths.get(h)
+            if source and os.path.isfile(source):
+                with open(source, "rb") as f, open(target, "wb") as g:
+                    g.write(f.read())
+    info["FileReplacements"] = {k: v for k, v in folded.values()}
+    info["ManipulationString"] = manipulation        # :477
+    if not glam["Entries"] or glam["Entries"][-1]["GlamourerString"] != glamourer:   # :479-492
+        glam["Entries"].append({"Timestamp": "<now>", "Description": "Glamourer Update - <now> UTC",
+                                "GlamourerString": glamourer})
+    b64 = base64.b64encode(customize.encode("utf-8")).decode("ascii") if customize else ""   # :494-496
+    if (not cust["Entries"] or cust["Entries"][-1]["CustomizeData"] != b64) and b64:         # :497-511
+        cust["Entries"].append({"Timestamp": "<now>", "Description": "Customize+ Update - <now> UTC",
+                                "CustomizeData": b64, "CustomizeTemplate": ""})
+    info["LastUpdate"] = "<now>"
+    for path, obj in ((info_path, info), (glam_path, glam), (cust_path, cust)):     # :672-695
+        with open(path, "w", encoding="utf-8") as f:
+            text = json.dumps(obj, indent=2, ensure_ascii=False)
+            # JsonConvert also escapes these three (StringEscapeHandling.Default)
+            for ch in ("\u0085", "\u2028", "\u2029"):
+                text = text.replace(ch, "\\u%04x" % ord(ch))
+            f.write(text)
+    return snapshot_dir

@@ -15,4 +15,4 @@ from .mcdf import (  # noqa: F401
     mcdf_write_header,
     write_mcdf,
 )
-from .snapshot import import_mcdf, store_files  # noqa: F401,E402
+from .snapshot import import_mcdf, store_files, update_snapshot  # noqa: F401,E402

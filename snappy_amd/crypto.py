@@ -93,6 +93,25 @@ def plan_shards(lengths, n_shards: int) -> np.ndarray:
     return cuts
 
 
+def plan_shards_lpt(lengths, n_shards: int):
+    """Longest-first dealing by padded blocks; returns (shard_of[n] uint32, blocks[n_shards] uint64)."""
+    ln = np.ascontiguousarray(lengths, dtype=np.uint64)
+    shard_of = np.zeros(ln.shape[0], dtype=np.uint32)
+    blocks = np.zeros(n_shards, dtype=np.uint64)
+    native.check(native.lib().snappy_plan_shards_lpt(ln.ctypes.data, ln.shape[0], n_shards,
+                                                     shard_of.ctypes.data, blocks.ctypes.data),
+                 "snappy_plan_shards_lpt")
+    return shard_of, blocks
+
+
+def device_work(device: int):
+    """(files or archives, bytes) the host-pointer entry points have given a device so far."""
+    u, b = ctypes.c_uint64(0), ctypes.c_uint64(0)
+    native.check(native.lib().snappy_device_work(device, ctypes.byref(u), ctypes.byref(b)),
+                 "snappy_device_work")
+    return u.value, b.value
+
+
 def sha1_batch_resident(device: int, d_base: int, d_offsets: int, d_lengths: int, n: int,
                         d_digests: int, stream: int = 0) -> None:
     """Everything in HBM: device addresses of the data, the two uint64 tables and the 20*n digest bytes."""

@@ -16,6 +16,7 @@
 #include "transfer.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 namespace snappy {
@@ -101,23 +102,67 @@ void parse_lz4net_stream(const uint8_t *in, uint64_t in_len, Lz4netLayout &layou
 int decode_streams_on_device(SlotLease &lease, std::vector<StreamJob> &jobs)
 {
     Slot &s = *lease.slot;
+    // A chunk header is a dozen bytes and may declare 2 GiB of output.  An LZ4 block
+    // cannot expand more than 255-fold (one length-extension byte stands for 255 output
+    // bytes), so a chunk that claims more can only fail to decode: it is reported as
+    // the corrupt block it is without reserving memory for its claim, and the walk ends
+    // there as the reader's would.
+    for (StreamJob &j : jobs) {
+        std::vector<Lz4Chunk> &chunks = j.layout.chunks;
+        for (size_t i = 0; i < chunks.size(); ++i)
+            if (chunks[i].compressed && chunks[i].orig_len > 255ull * chunks[i].comp_len) {
+                j.layout.decoded_size = chunks[i].out_off;
+                j.layout.stop_status = SNAPPY_E_LZ4_CORRUPT;
+                chunks.resize(i);
+                break;
+            }
+    }
     // Device arena: [stream 0 | slack][stream 1 | slack]...[payload 0][payload 1]...
     // The slack lets the decoder's input window read whole dwords past a stream's
-    // last byte; every region starts on a 256-byte boundary.
-    uint64_t cursor = 0, n_chunks = 0;
-    for (StreamJob &j : jobs) {
-        j.in_off = cursor;
-        cursor += (j.in_len + 256 + 255) & ~uint64_t(255);
-        n_chunks += j.layout.chunks.size();
-    }
-    const uint64_t in_alloc = cursor;
-    for (StreamJob &j : jobs) {
-        j.out_off = cursor;
-        cursor += (j.layout.decoded_size + 255) & ~uint64_t(255);
+    // last byte; every region starts on a 256-byte boundary.  When the arena cannot
+    // be had, the stream that asks for the most is given up (SNAPPY_E_NOMEM for it
+    // alone) and the others are tried again: one oversized archive does not take the
+    // batch down with it.
+    uint64_t cursor = 0, n_chunks = 0, in_alloc = 0;
+    // SNAPPY_TEST_ARENA_LIMIT_BYTES: tests of that path (an arena above it counts as refused).
+    const char *limit_text = std::getenv("SNAPPY_TEST_ARENA_LIMIT_BYTES");
+    const uint64_t test_limit = limit_text ? std::strtoull(limit_text, nullptr, 10) : 0;
+    for (;;) {
+        cursor = 0;
+        n_chunks = 0;
+        for (StreamJob &j : jobs) {
+            j.in_off = cursor;
+            if (j.dropped)
+                continue;
+            cursor += (j.in_len + 256 + 255) & ~uint64_t(255);
+            n_chunks += j.layout.chunks.size();
+        }
+        in_alloc = cursor;
+        for (StreamJob &j : jobs) {
+            j.out_off = cursor;
+            if (!j.dropped)
+                cursor += (j.layout.decoded_size + 255) & ~uint64_t(255);
+        }
+        int st = (test_limit && cursor > test_limit) ? SNAPPY_E_NOMEM
+                                                     : s.d_data.ensure(static_cast<size_t>(cursor + 64));
+        if (st == SNAPPY_OK)
+            break;
+        StreamJob *largest = nullptr;
+        size_t alive = 0;
+        for (StreamJob &j : jobs)
+            if (!j.dropped) {
+                ++alive;
+                if (!largest || j.in_len + j.layout.decoded_size > largest->in_len + largest->layout.decoded_size)
+                    largest = &j;
+            }
+        if (st != SNAPPY_E_NOMEM || alive <= 1)
+            return st;
+        largest->dropped = true;
+        largest->layout.chunks.clear();
+        largest->layout.decoded_size = 0;
+        largest->layout.stop_status = SNAPPY_E_NOMEM;
     }
     int st;
-    if ((st = s.d_data.ensure(static_cast<size_t>(cursor + 64))) != SNAPPY_OK)
-        return st;
     uint8_t *arena = static_cast<uint8_t *>(s.d_data.ptr);
     for (StreamJob &j : jobs) {
         j.d_payload = arena + j.out_off;
@@ -140,6 +185,8 @@ int decode_streams_on_device(SlotLease &lease, std::vector<StreamJob> &jobs)
     uint64_t k = 0;
     std::vector<Piece> pieces;
     for (StreamJob &j : jobs) {
+        if (j.dropped)
+            continue;
         const uint64_t region = (j.in_len + 256 + 255) & ~uint64_t(255);
         SNAPPY_HIP_TRY(hipMemsetAsync(arena + j.in_off + j.in_len, 0, region - j.in_len, stream));
         if (j.in_len)
@@ -209,49 +256,53 @@ using namespace snappy;
 
 extern "C" int snappy_lz4net_decoded_size(const uint8_t *in, uint64_t in_len, uint64_t *out_len)
 {
-    if (!out_len || (!in && in_len))
-        return SNAPPY_E_INVALID_ARG;
-    Lz4netLayout layout;
-    parse_lz4net_stream(in, in_len, layout);
-    if (layout.stop_status != SNAPPY_OK)
-        return layout.stop_status;
-    *out_len = layout.decoded_size;
-    return SNAPPY_OK;
+    return abi_guard([&]() -> int {
+        if (!out_len || (!in && in_len))
+            return SNAPPY_E_INVALID_ARG;
+        Lz4netLayout layout;
+        parse_lz4net_stream(in, in_len, layout);
+        if (layout.stop_status != SNAPPY_OK)
+            return layout.stop_status;
+        *out_len = layout.decoded_size;
+        return SNAPPY_OK;
+    });
 }
 
 extern "C" int snappy_lz4net_decode(const uint8_t *in, uint64_t in_len, uint8_t *out,
                                     uint64_t out_cap, uint64_t *out_len)
 {
-    if (!out_len || (!in && in_len) || (!out && out_cap))
-        return SNAPPY_E_INVALID_ARG;
-    Lz4netLayout layout;
-    parse_lz4net_stream(in, in_len, layout);
-    // The reader meets chunks in order: a chunk that does not fit the caller's
-    // buffer ends the walk there, before any later structural error.
-    uint64_t total = 0;
-    for (size_t i = 0; i < layout.chunks.size(); ++i) {
-        if (total + layout.chunks[i].orig_len > out_cap) {
-            layout.chunks.resize(i);
-            layout.stop_status = SNAPPY_E_CAPACITY;
-            break;
+    return abi_guard([&]() -> int {
+        if (!out_len || (!in && in_len) || (!out && out_cap))
+            return SNAPPY_E_INVALID_ARG;
+        Lz4netLayout layout;
+        parse_lz4net_stream(in, in_len, layout);
+        // The reader meets chunks in order: a chunk that does not fit the caller's
+        // buffer ends the walk there, before any later structural error.
+        uint64_t total = 0;
+        for (size_t i = 0; i < layout.chunks.size(); ++i) {
+            if (total + layout.chunks[i].orig_len > out_cap) {
+                layout.chunks.resize(i);
+                layout.stop_status = SNAPPY_E_CAPACITY;
+                break;
+            }
+            total += layout.chunks[i].orig_len;
         }
-        total += layout.chunks[i].orig_len;
-    }
-    layout.decoded_size = total;
+        layout.decoded_size = total;
 
-    SlotLease lease;
-    int st = lease.acquire(pick_device());
-    if (st != SNAPPY_OK)
-        return st;
-    profile_reset();
-    DecodedOnDevice dec;
-    st = decode_lz4net_on_device(lease, in, in_len, layout, dec);
-    if (st != SNAPPY_OK)
-        return st;
-    if (dec.size)
-        SNAPPY_HIP_TRY(transfer_to_host(*lease.slot, lease.dev->hip_device, dec.d_payload, out, dec.size));
-    *out_len = dec.size;
-    return SNAPPY_OK;
+        SlotLease lease;
+        int st = lease.acquire(pick_device());
+        if (st != SNAPPY_OK)
+            return st;
+        profile_reset();
+        DecodedOnDevice dec;
+        st = decode_lz4net_on_device(lease, in, in_len, layout, dec);
+        if (st != SNAPPY_OK)
+            return st;
+        if (dec.size)
+            SNAPPY_HIP_TRY(transfer_to_host(*lease.slot, lease.dev->hip_device, dec.d_payload, out, dec.size));
+        *out_len = dec.size;
+        return SNAPPY_OK;
+    });
 }
 
 // ---------------------------------------------------------------------------
@@ -286,116 +337,120 @@ constexpr uint32_t kMaxBlockSize = 1u << 30;
 
 extern "C" int snappy_lz4net_encode_bound(uint64_t in_len, uint32_t block_size, uint64_t *bound)
 {
-    if (!bound || block_size > kMaxBlockSize)
-        return SNAPPY_E_INVALID_ARG;
-    const uint64_t bs = block_size ? block_size : kDefaultBlockSize;
-    const uint64_t chunks = (in_len + bs - 1) / bs;
-    *bound = in_len + chunks * 16 + 16;
-    return SNAPPY_OK;
+    return abi_guard([&]() -> int {
+        if (!bound || block_size > kMaxBlockSize)
+            return SNAPPY_E_INVALID_ARG;
+        const uint64_t bs = block_size ? block_size : kDefaultBlockSize;
+        const uint64_t chunks = (in_len + bs - 1) / bs;
+        *bound = in_len + chunks * 16 + 16;
+        return SNAPPY_OK;
+    });
 }
 
 extern "C" int snappy_lz4net_encode(const uint8_t *in, uint64_t in_len, uint32_t block_size,
                                     uint8_t *out, uint64_t out_cap, uint64_t *out_len)
 {
-    if ((!in && in_len) || !out_len || (!out && out_cap) || block_size > kMaxBlockSize)
-        return SNAPPY_E_INVALID_ARG;
-    *out_len = 0;
-    if (in_len == 0)
-        return SNAPPY_OK;  // LZ4Stream writes nothing for an empty input
-    const uint64_t bs = block_size ? block_size : kDefaultBlockSize;
-    const uint64_t n_chunks = (in_len + bs - 1) / bs;
-    if (n_chunks >= 0x7FFFFFFFull)
-        return SNAPPY_E_INVALID_ARG;
+    return abi_guard([&]() -> int {
+        if ((!in && in_len) || !out_len || (!out && out_cap) || block_size > kMaxBlockSize)
+            return SNAPPY_E_INVALID_ARG;
+        *out_len = 0;
+        if (in_len == 0)
+            return SNAPPY_OK;  // LZ4Stream writes nothing for an empty input
+        const uint64_t bs = block_size ? block_size : kDefaultBlockSize;
+        const uint64_t n_chunks = (in_len + bs - 1) / bs;
+        if (n_chunks >= 0x7FFFFFFFull)
+            return SNAPPY_E_INVALID_ARG;
 
-    SlotLease lease;
-    int st = lease.acquire(pick_device());
-    if (st != SNAPPY_OK)
-        return st;
-    Slot &s = *lease.slot;
-    profile_reset();
+        SlotLease lease;
+        int st = lease.acquire(pick_device());
+        if (st != SNAPPY_OK)
+            return st;
+        Slot &s = *lease.slot;
+        profile_reset();
 
-    // Arena: [input][one worst-case output area per chunk][the finished stream].
-    const uint64_t area = (bs + bs / 255 + 16 + 15) & ~uint64_t(15);
-    const uint64_t in_area = (in_len + 15) & ~uint64_t(15);
-    const uint64_t stream_at = in_area + n_chunks * area;
-    const uint64_t stream_room = in_len + 16 * n_chunks + 256;  // headers are at most 11 bytes per chunk
-    std::vector<Lz4EncChunk> chunks(n_chunks);
-    for (uint64_t k = 0; k < n_chunks; ++k) {
-        chunks[k].in_off = k * bs;
-        chunks[k].out_off = in_area + k * area;
-        chunks[k].in_len = static_cast<uint32_t>(std::min<uint64_t>(bs, in_len - k * bs));
-        chunks[k].reserved = 0;
-    }
-    if ((st = s.d_data.ensure(stream_at + stream_room)) != SNAPPY_OK) return st;
-    if ((st = s.d_tasks.ensure(n_chunks * sizeof(Lz4EncChunk))) != SNAPPY_OK) return st;
-    if ((st = s.d_tables.ensure(n_chunks * sizeof(Lz4PackItem))) != SNAPPY_OK) return st;
-    if ((st = s.d_out.ensure(n_chunks * sizeof(uint32_t))) != SNAPPY_OK) return st;
-    uint8_t *d_base = static_cast<uint8_t *>(s.d_data.ptr);
-    Lz4EncChunk *d_chunks = static_cast<Lz4EncChunk *>(s.d_tasks.ptr);
-    uint32_t *d_sizes = static_cast<uint32_t *>(s.d_out.ptr);
-    {
-        std::vector<Piece> pieces{{in, 0, in_len}};
-        SNAPPY_HIP_TRY(transfer_to_device(s, lease.dev->hip_device, pieces, kTransferSliceBytes, d_base,
-                                          nullptr, nullptr));
-    }
-    SNAPPY_HIP_TRY(hipMemcpyAsync(d_chunks, chunks.data(), n_chunks * sizeof(Lz4EncChunk),
-                                  hipMemcpyHostToDevice, s.stream));
-    const bool prof = profiling_enabled();
-    if (prof)
-        SNAPPY_HIP_TRY(hipEventRecord(s.ev_prof[1][0], s.stream));
-    SNAPPY_HIP_TRY(launch_lz4_encode(d_base, d_base, d_chunks, static_cast<uint32_t>(n_chunks),
-                                     d_sizes, s.stream));
-    if (prof)
-        SNAPPY_HIP_TRY(hipEventRecord(s.ev_prof[1][1], s.stream));
-    std::vector<uint32_t> sizes(n_chunks);
-    SNAPPY_HIP_TRY(hipMemcpyAsync(sizes.data(), d_sizes, n_chunks * sizeof(uint32_t),
-                                  hipMemcpyDeviceToHost, s.stream));
-    SNAPPY_HIP_TRY(hipStreamSynchronize(s.stream));
-    if (prof) {
-        float ms = -1.f;
-        if (hipEventElapsedTime(&ms, s.ev_prof[1][0], s.ev_prof[1][1]) == hipSuccess)
-            profile_store(1, ms);
-        else
-            (void)hipGetLastError();
-    }
+        // Arena: [input][one worst-case output area per chunk][the finished stream].
+        const uint64_t area = (bs + bs / 255 + 16 + 15) & ~uint64_t(15);
+        const uint64_t in_area = (in_len + 15) & ~uint64_t(15);
+        const uint64_t stream_at = in_area + n_chunks * area;
+        const uint64_t stream_room = in_len + 16 * n_chunks + 256;  // headers are at most 11 bytes per chunk
+        std::vector<Lz4EncChunk> chunks(n_chunks);
+        for (uint64_t k = 0; k < n_chunks; ++k) {
+            chunks[k].in_off = k * bs;
+            chunks[k].out_off = in_area + k * area;
+            chunks[k].in_len = static_cast<uint32_t>(std::min<uint64_t>(bs, in_len - k * bs));
+            chunks[k].reserved = 0;
+        }
+        if ((st = s.d_data.ensure(stream_at + stream_room)) != SNAPPY_OK) return st;
+        if ((st = s.d_tasks.ensure(n_chunks * sizeof(Lz4EncChunk))) != SNAPPY_OK) return st;
+        if ((st = s.d_tables.ensure(n_chunks * sizeof(Lz4PackItem))) != SNAPPY_OK) return st;
+        if ((st = s.d_out.ensure(n_chunks * sizeof(uint32_t))) != SNAPPY_OK) return st;
+        uint8_t *d_base = static_cast<uint8_t *>(s.d_data.ptr);
+        Lz4EncChunk *d_chunks = static_cast<Lz4EncChunk *>(s.d_tasks.ptr);
+        uint32_t *d_sizes = static_cast<uint32_t *>(s.d_out.ptr);
+        {
+            std::vector<Piece> pieces{{in, 0, in_len}};
+            SNAPPY_HIP_TRY(transfer_to_device(s, lease.dev->hip_device, pieces, kTransferSliceBytes, d_base,
+                                              nullptr, nullptr));
+        }
+        SNAPPY_HIP_TRY(hipMemcpyAsync(d_chunks, chunks.data(), n_chunks * sizeof(Lz4EncChunk),
+                                      hipMemcpyHostToDevice, s.stream));
+        const bool prof = profiling_enabled();
+        if (prof)
+            SNAPPY_HIP_TRY(hipEventRecord(s.ev_prof[1][0], s.stream));
+        SNAPPY_HIP_TRY(launch_lz4_encode(d_base, d_base, d_chunks, static_cast<uint32_t>(n_chunks),
+                                         d_sizes, s.stream));
+        if (prof)
+            SNAPPY_HIP_TRY(hipEventRecord(s.ev_prof[1][1], s.stream));
+        std::vector<uint32_t> sizes(n_chunks);
+        SNAPPY_HIP_TRY(hipMemcpyAsync(sizes.data(), d_sizes, n_chunks * sizeof(uint32_t),
+                                      hipMemcpyDeviceToHost, s.stream));
+        SNAPPY_HIP_TRY(hipStreamSynchronize(s.stream));
+        if (prof) {
+            float ms = -1.f;
+            if (hipEventElapsedTime(&ms, s.ev_prof[1][0], s.ev_prof[1][1]) == hipSuccess)
+                profile_store(1, ms);
+            else
+                (void)hipGetLastError();
+        }
 
-    // FlushCurrentChunk: flags (bit 0 = compressed), original length, compressed
-    // length when compressed, payload; a block that does not shrink is stored.
-    uint64_t need = 0;
-    for (uint64_t k = 0; k < n_chunks; ++k) {
-        const uint64_t n = chunks[k].in_len, c = sizes[k];
-        need += 1 + varint_size(n) + (c < n ? varint_size(c) + c : n);
-    }
-    *out_len = need;
-    if (need > out_cap)
-        return SNAPPY_E_CAPACITY;
-    // The payloads are gathered at their places in the stream on the device, the
-    // stream comes back in one transfer, and the headers are written into the gaps.
-    std::vector<Lz4PackItem> items(n_chunks);
-    uint64_t o = 0;
-    for (uint64_t k = 0; k < n_chunks; ++k) {
-        const uint64_t n = chunks[k].in_len, c = sizes[k];
-        const bool compressed = c < n;
-        o += 1 + varint_size(n) + (compressed ? varint_size(c) : 0);
-        items[k] = {compressed ? chunks[k].out_off : chunks[k].in_off, stream_at + o, compressed ? c : n};
-        o += items[k].len;
-    }
-    Lz4PackItem *d_items = static_cast<Lz4PackItem *>(s.d_tables.ptr);
-    SNAPPY_HIP_TRY(hipMemcpyAsync(d_items, items.data(), n_chunks * sizeof(Lz4PackItem),
-                                  hipMemcpyHostToDevice, s.stream));
-    SNAPPY_HIP_TRY(launch_lz4_pack(d_base, d_items, static_cast<uint32_t>(n_chunks), s.stream));
-    SNAPPY_HIP_TRY(hipStreamSynchronize(s.stream));
-    SNAPPY_HIP_TRY(transfer_to_host(s, lease.dev->hip_device, d_base + stream_at, out, need));
-    o = 0;
-    for (uint64_t k = 0; k < n_chunks; ++k) {
-        const uint64_t n = chunks[k].in_len, c = sizes[k];
-        const bool compressed = c < n;
-        o = put_varint(out, o, compressed ? 1u : 0u);
-        o = put_varint(out, o, n);
-        if (compressed)
-            o = put_varint(out, o, c);
-        o += items[k].len;
-    }
-    SNAPPY_HIP_TRY(hipStreamSynchronize(s.stream));
-    return SNAPPY_OK;
+        // FlushCurrentChunk: flags (bit 0 = compressed), original length, compressed
+        // length when compressed, payload; a block that does not shrink is stored.
+        uint64_t need = 0;
+        for (uint64_t k = 0; k < n_chunks; ++k) {
+            const uint64_t n = chunks[k].in_len, c = sizes[k];
+            need += 1 + varint_size(n) + (c < n ? varint_size(c) + c : n);
+        }
+        *out_len = need;
+        if (need > out_cap)
+            return SNAPPY_E_CAPACITY;
+        // The payloads are gathered at their places in the stream on the device, the
+        // stream comes back in one transfer, and the headers are written into the gaps.
+        std::vector<Lz4PackItem> items(n_chunks);
+        uint64_t o = 0;
+        for (uint64_t k = 0; k < n_chunks; ++k) {
+            const uint64_t n = chunks[k].in_len, c = sizes[k];
+            const bool compressed = c < n;
+            o += 1 + varint_size(n) + (compressed ? varint_size(c) : 0);
+            items[k] = {compressed ? chunks[k].out_off : chunks[k].in_off, stream_at + o, compressed ? c : n};
+            o += items[k].len;
+        }
+        Lz4PackItem *d_items = static_cast<Lz4PackItem *>(s.d_tables.ptr);
+        SNAPPY_HIP_TRY(hipMemcpyAsync(d_items, items.data(), n_chunks * sizeof(Lz4PackItem),
+                                      hipMemcpyHostToDevice, s.stream));
+        SNAPPY_HIP_TRY(launch_lz4_pack(d_base, d_items, static_cast<uint32_t>(n_chunks), s.stream));
+        SNAPPY_HIP_TRY(hipStreamSynchronize(s.stream));
+        SNAPPY_HIP_TRY(transfer_to_host(s, lease.dev->hip_device, d_base + stream_at, out, need));
+        o = 0;
+        for (uint64_t k = 0; k < n_chunks; ++k) {
+            const uint64_t n = chunks[k].in_len, c = sizes[k];
+            const bool compressed = c < n;
+            o = put_varint(out, o, compressed ? 1u : 0u);
+            o = put_varint(out, o, n);
+            if (compressed)
+                o = put_varint(out, o, c);
+            o += items[k].len;
+        }
+        SNAPPY_HIP_TRY(hipStreamSynchronize(s.stream));
+        return SNAPPY_OK;
+    });
 }

@@ -39,6 +39,7 @@ struct StreamJob {
     uint64_t out_off = 0;  // of its payload in the arena
     uint8_t *d_payload = nullptr;
     int status = SNAPPY_OK;
+    bool dropped = false;  // given up for lack of device memory (status SNAPPY_E_NOMEM)
 };
 
 // Uploads all streams and decodes all their chunks in one launch, so that a

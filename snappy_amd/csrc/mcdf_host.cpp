@@ -8,20 +8,13 @@
 #include <utility>
 
 #include "../../include/snappyhash.h"
+#include "abi_guard.hpp"
 
 namespace snappy {
 
 namespace {
 
 // ---------------------------------------------------------------- tiny JSON DOM
-struct JsonValue {
-    enum Kind { Null, Bool, Number, String, Array, Object } kind = Null;
-    bool boolean = false;
-    std::string text;  // String: decoded UTF-8; Number: the literal
-    std::vector<JsonValue> items;
-    std::vector<std::pair<std::string, JsonValue>> members;
-};
-
 class JsonParser {
 public:
     JsonParser(const char *p, size_t n) : p_(p), end_(p + n) {}
@@ -39,6 +32,10 @@ private:
     const char *p_;
     const char *end_;
     static constexpr int kMaxDepth = 64;
+    // A value costs ~100 bytes of DOM however small its text: "[[],[],..." would turn
+    // a 2 GiB header into tens of GiB.  A real header has a few thousand values.
+    static constexpr size_t kMaxValues = size_t(1) << 20;
+    size_t n_values_ = 0;
 
     void skip_ws()
     {
@@ -180,7 +177,7 @@ private:
 
     bool parse_value(JsonValue &out, int depth)
     {
-        if (depth > kMaxDepth || p_ >= end_)
+        if (depth > kMaxDepth || p_ >= end_ || ++n_values_ > kMaxValues)
             return false;
         const char c = *p_;
         if (c == '{') {
@@ -284,8 +281,6 @@ bool ascii_iequals(const std::string &a, const char *b)
     return true;
 }
 
-// Property binding the way the managed deserializer does it: exact name first,
-// then case-insensitive; the last duplicate wins.
 const JsonValue *member(const JsonValue &obj, const char *name)
 {
     const JsonValue *exact = nullptr, *loose = nullptr;
@@ -344,6 +339,14 @@ bool to_int64(const JsonValue &v, int64_t &out)
 }
 
 }  // namespace
+
+bool parse_json(const char *text, size_t n, JsonValue &out)
+{
+    JsonParser parser(text, n);
+    return parser.parse_document(out);
+}
+
+const JsonValue *json_member(const JsonValue &obj, const char *name) { return member(obj, name); }
 
 int mcdf_header_extent(const uint8_t *payload, uint64_t avail, uint64_t payload_len, uint64_t *need)
 {
@@ -451,21 +454,23 @@ extern "C" int snappy_mcdf_parse_header(const uint8_t *payload, uint64_t payload
                                         uint64_t *n_files, uint64_t *body_offset,
                                         int64_t *file_lengths, uint64_t lengths_cap)
 {
-    if (!n_files || !body_offset || (!payload && payload_len))
-        return SNAPPY_E_INVALID_ARG;
-    if (!payload)
-        return SNAPPY_E_MCDF_MAGIC;
-    McdfHeaderInfo info;
-    int st = parse_mcdf_header(payload, payload_len, info);
-    if (st != SNAPPY_OK)
-        return st;
-    *n_files = info.files.size();
-    *body_offset = info.body_offset;
-    if (file_lengths) {
-        if (lengths_cap < info.files.size())
-            return SNAPPY_E_CAPACITY;
-        for (size_t i = 0; i < info.files.size(); ++i)
-            file_lengths[i] = info.files[i].length;
-    }
-    return SNAPPY_OK;
+    return abi_guard([&]() -> int {
+        if (!n_files || !body_offset || (!payload && payload_len))
+            return SNAPPY_E_INVALID_ARG;
+        if (!payload)
+            return SNAPPY_E_MCDF_MAGIC;
+        McdfHeaderInfo info;
+        int st = parse_mcdf_header(payload, payload_len, info);
+        if (st != SNAPPY_OK)
+            return st;
+        *n_files = info.files.size();
+        *body_offset = info.body_offset;
+        if (file_lengths) {
+            if (lengths_cap < info.files.size())
+                return SNAPPY_E_CAPACITY;
+            for (size_t i = 0; i < info.files.size(); ++i)
+                file_lengths[i] = info.files[i].length;
+        }
+        return SNAPPY_OK;
+    });
 }

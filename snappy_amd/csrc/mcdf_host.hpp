@@ -9,9 +9,25 @@
 #include <stdint.h>
 
 #include <string>
+#include <utility>
 #include <vector>
 
 namespace snappy {
+
+// The small JSON document model the header parser uses (strict RFC 8259; at most
+// 64 levels and 2^20 values).  Also read by the snapshot-folder code, which takes
+// an existing snapshot.json and the two history files back in.
+struct JsonValue {
+    enum Kind { Null, Bool, Number, String, Array, Object } kind = Null;
+    bool boolean = false;
+    std::string text;  // String: decoded UTF-8; Number: the literal
+    std::vector<JsonValue> items;
+    std::vector<std::pair<std::string, JsonValue>> members;
+};
+bool parse_json(const char *text, size_t n, JsonValue &out);
+// Property binding the way the managed deserializer does it: exact name first,
+// then case-insensitive; the last duplicate wins.  Null when absent.
+const JsonValue *json_member(const JsonValue &obj, const char *name);
 
 struct McdfFileEntry {
     std::vector<std::string> game_paths;  // FileData.GamePaths

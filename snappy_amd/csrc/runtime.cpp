@@ -262,13 +262,16 @@ using namespace snappy;
 
 extern "C" int snappy_init(int n_devices)
 {
-    std::lock_guard<std::mutex> lk(g_init_mu);
-    return init_locked(n_devices);
+    return abi_guard([&]() -> int {
+        std::lock_guard<std::mutex> lk(g_init_mu);
+        return init_locked(n_devices);
+    });
 }
 
 extern "C" void snappy_shutdown(void)
 {
     std::lock_guard<std::mutex> lk(g_init_mu);
+    release_file_arena();
     for (auto &d : g_devices) {
         (void)hipSetDevice(d->hip_device);
         for (auto &s : d->slots)
@@ -284,31 +287,35 @@ extern "C" int snappy_device_count(void) { return device_count(); }
 
 extern "C" int snappy_host_alloc(uint64_t bytes, void **out)
 {
-    if (!out)
-        return SNAPPY_E_INVALID_ARG;
-    *out = nullptr;
-    int st = ensure_initialized();
-    if (st != SNAPPY_OK)
-        return st;
-    if (bytes == 0)
-        return SNAPPY_OK;
-    // Portable: page-locked for every device, whichever one the data ends up on.
-    hipError_t e = hipHostMalloc(out, static_cast<size_t>(bytes), hipHostMallocPortable);
-    if (e != hipSuccess) {
-        (void)hipGetLastError();
+    return abi_guard([&]() -> int {
+        if (!out)
+            return SNAPPY_E_INVALID_ARG;
         *out = nullptr;
-        set_error_detail(std::string("hipHostMalloc: ") + hipGetErrorString(e));
-        return SNAPPY_E_NOMEM;
-    }
-    return SNAPPY_OK;
+        int st = ensure_initialized();
+        if (st != SNAPPY_OK)
+            return st;
+        if (bytes == 0)
+            return SNAPPY_OK;
+        // Portable: page-locked for every device, whichever one the data ends up on.
+        hipError_t e = hipHostMalloc(out, static_cast<size_t>(bytes), hipHostMallocPortable);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            *out = nullptr;
+            set_error_detail(std::string("hipHostMalloc: ") + hipGetErrorString(e));
+            return SNAPPY_E_NOMEM;
+        }
+        return SNAPPY_OK;
+    });
 }
 
 extern "C" int snappy_host_free(void *ptr)
 {
-    if (!ptr)
+    return abi_guard([&]() -> int {
+        if (!ptr)
+            return SNAPPY_OK;
+        SNAPPY_HIP_TRY(hipHostFree(ptr));
         return SNAPPY_OK;
-    SNAPPY_HIP_TRY(hipHostFree(ptr));
-    return SNAPPY_OK;
+    });
 }
 
 extern "C" const char *snappy_strerror(int code)
@@ -328,6 +335,8 @@ extern "C" const char *snappy_strerror(int code)
     case SNAPPY_E_MCDF_VERSION: return "Unsupported MCDF version";
     case SNAPPY_E_MCDF_TRUNCATED: return "MCDF payload ends inside the header";
     case SNAPPY_E_MCDF_JSON: return "MCDF header JSON is malformed";
+    case SNAPPY_E_SNAPSHOT_JSON: return "an existing snapshot JSON file does not deserialize";
+    case SNAPPY_E_MCDF_BASE64: return "The input is not a valid Base-64 string";
     default: return "unknown status";
     }
 }

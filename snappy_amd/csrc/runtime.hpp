@@ -15,10 +15,15 @@
 #include <condition_variable>
 #include <memory>
 #include <mutex>
+#include <new>
+#include <stdexcept>
 #include <string>
+#include <thread>
+#include <utility>
 #include <vector>
 
 #include "../../include/snappyhash.h"
+#include "abi_guard.hpp"
 
 namespace snappy {
 
@@ -32,6 +37,20 @@ void set_error_detail(const std::string &s);
             return (_e == hipErrorOutOfMemory) ? SNAPPY_E_NOMEM : SNAPPY_E_HIP;           \
         }                                                                                 \
     } while (0)
+
+// Starts fn on a new thread of `pool`.  False when the system has no thread to
+// give: the caller then does that work itself, or with the threads it has (a
+// pool that went out of scope with running threads would end the process).
+template <typename Fn>
+bool try_spawn(std::vector<std::thread> &pool, Fn &&fn) noexcept
+{
+    try {
+        pool.emplace_back(std::forward<Fn>(fn));
+        return true;
+    } catch (...) {
+        return false;
+    }
+}
 
 // Grow-only device or pinned-host buffer owned by a slot.
 struct Buffer {
@@ -63,6 +82,9 @@ struct Slot {
 struct DeviceCtx {
     int hip_device = 0;
     int n_cu = 0;
+    // Host-pointer work this device has been given since it was bound (files or
+    // archives, and their bytes): what snappy_device_work reports.
+    std::atomic<uint64_t> work_units{0}, work_bytes{0};
     std::mutex mu;
     std::condition_variable cv;
     std::vector<std::unique_ptr<Slot>> slots;
@@ -86,6 +108,7 @@ int pick_device();                 // round-robin choice for single-buffer calls
 // The bound device `device`, or null when the library is not initialised or the
 // index is out of range.  Initialises nothing and allocates nothing.
 DeviceCtx *bound_device(int device);
+void release_file_arena();         // host_mirror.cpp: the page-locked arena file contents are read into
 bool profiling_enabled();
 void profile_reset();
 void profile_store(int kernel, float ms);

@@ -340,6 +340,8 @@ int hash_ranges_on_device(int device, const HostRange *ranges, uint64_t first, u
     uint64_t total = 0;
     for (uint64_t i = 0; i < n; ++i)
         total += ranges[first + i].len;
+    lease.dev->work_units += n;
+    lease.dev->work_bytes += total;
     // SNAPPY_OVERLAP_MIN_BYTES / SNAPPY_OVERLAP_SLICE_BYTES: tests and tuning.
     const uint64_t min_bytes =
         static_cast<uint64_t>(env_long("SNAPPY_OVERLAP_MIN_BYTES", 64L << 20));
@@ -355,9 +357,11 @@ int hash_ranges_on_device(int device, const HostRange *ranges, uint64_t first, u
     std::atomic<bool> &busy = waiting_kernel[lease.dev->hip_device % kMaxHipDevices];
     if (busy.exchange(true))
         return hash_ranges_serial(lease, ranges, first, n, digests, gate);
-    st = hash_ranges_overlapped(lease, ranges, first, n, slice, digests, gate);
-    busy.store(false);
-    return st;
+    struct Release {
+        std::atomic<bool> &flag;
+        ~Release() { flag.store(false); }
+    } release{busy};
+    return hash_ranges_overlapped(lease, ranges, first, n, slice, digests, gate);
 }
 
 }  // namespace
@@ -380,10 +384,56 @@ void plan_shards(const uint64_t *lengths, uint64_t n, uint32_t n_shards, uint64_
     }
 }
 
+// Longest processing time first, by padded 64-byte blocks (what a file costs the
+// kernel): files at least 1/64 of a device's share are sorted by size and each goes
+// to the device with the fewest blocks so far; the many small ones that remain are
+// then dealt out in caller order as contiguous runs that fill each device up to the
+// average, so that neighbours in host memory still travel as one transfer.  A
+// device ends within one such small file (under 1/64 of the average) of the
+// sorted-list bound.
+void plan_shards_lpt(const uint64_t *lengths, uint64_t n, uint32_t n_shards, uint32_t *shard_of,
+                     uint64_t *shard_blocks)
+{
+    std::vector<uint64_t> load(n_shards, 0);
+    auto blocks_of = [&](uint64_t i) { return (lengths[i] + 8) / 64 + 1; };
+    uint64_t total = 0;
+    for (uint64_t i = 0; i < n; ++i)
+        total += blocks_of(i);
+    const uint64_t average = (total + n_shards - 1) / n_shards;
+    const uint64_t large_from = std::max<uint64_t>(1, average / 64);
+    std::vector<uint64_t> large;
+    for (uint64_t i = 0; i < n; ++i)
+        if (blocks_of(i) >= large_from)
+            large.push_back(i);
+    std::stable_sort(large.begin(), large.end(),
+                     [&](uint64_t x, uint64_t y) { return blocks_of(x) > blocks_of(y); });
+    for (uint64_t i : large) {
+        uint32_t best = 0;
+        for (uint32_t k = 1; k < n_shards; ++k)
+            if (load[k] < load[best])
+                best = k;
+        shard_of[i] = best;
+        load[best] += blocks_of(i);
+    }
+    uint32_t k = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        if (blocks_of(i) >= large_from)
+            continue;
+        while (k + 1 < n_shards && load[k] >= average)
+            ++k;
+        shard_of[i] = k;
+        load[k] += blocks_of(i);
+    }
+    if (shard_blocks)
+        for (uint32_t q = 0; q < n_shards; ++q)
+            shard_blocks[q] = load[q];
+}
+
 namespace {
 
-// Files are independent, so a batch shards across devices with no exchange:
-// contiguous groups of near-equal byte count, one host thread per device.
+// Files are independent, so a batch shards across devices with no exchange: the
+// files are dealt out by plan_shards_lpt, one host thread per device hashes its
+// share on that device, and the digests return to the caller's order.
 int hash_ranges(const std::vector<HostRange> &ranges, uint8_t *digests, SourceGate *gate = nullptr)
 {
     const uint64_t n = ranges.size();
@@ -400,29 +450,61 @@ int hash_ranges(const std::vector<HostRange> &ranges, uint8_t *digests, SourceGa
     for (const HostRange &r : ranges)
         total += r.len;
     const uint64_t min_shard_bytes = 8ull << 20;
-    int shards = static_cast<int>(
+    const int shards = static_cast<int>(
         std::min<uint64_t>(std::min<uint64_t>(n, static_cast<uint64_t>(n_dev)),
                            std::max<uint64_t>(1, total / min_shard_bytes)));
-    if (shards <= 1)
+    if (shards <= 1) {
         return hash_ranges_on_device(pick_device(), ranges.data(), 0, n, digests, gate);
+    }
 
     std::vector<uint64_t> lens(n);
     for (uint64_t i = 0; i < n; ++i)
         lens[i] = ranges[i].len;
-    std::vector<uint64_t> cut(static_cast<size_t>(shards) + 1, n);
-    plan_shards(lens.data(), n, static_cast<uint32_t>(shards), cut.data());
+    std::vector<uint32_t> shard_of(n);
+    plan_shards_lpt(lens.data(), n, static_cast<uint32_t>(shards), shard_of.data(), nullptr);
+    // Each device's files, in caller order.
+    std::vector<std::vector<uint32_t>> members(static_cast<size_t>(shards));
+    for (uint64_t i = 0; i < n; ++i)
+        members[shard_of[i]].push_back(static_cast<uint32_t>(i));
+
     std::vector<int> status(static_cast<size_t>(shards), SNAPPY_OK);
-    std::vector<std::thread> workers;
-    for (int d = 0; d < shards; ++d) {
-        workers.emplace_back([&, d] {
-            const uint64_t a = cut[static_cast<size_t>(d)], b = cut[static_cast<size_t>(d) + 1];
-            if (b > a)
-                status[static_cast<size_t>(d)] =
-                    hash_ranges_on_device(d, ranges.data(), a, b, digests, gate);
+    std::vector<float> shard_ms(static_cast<size_t>(shards), -1.f);
+    auto run_shard = [&](int d) {
+        const std::vector<uint32_t> &mine = members[static_cast<size_t>(d)];
+        if (mine.empty())
+            return;
+        status[static_cast<size_t>(d)] = abi_guard([&]() -> int {
+            std::vector<HostRange> sub(mine.size());
+            for (size_t k = 0; k < mine.size(); ++k)
+                sub[k] = ranges[mine[k]];
+            std::vector<uint8_t> local(mine.size() * 20);
+            profile_reset();
+            const int rc = hash_ranges_on_device(d, sub.data(), 0, sub.size(), local.data(), gate);
+            if (rc != SNAPPY_OK)
+                return rc;
+            for (size_t k = 0; k < mine.size(); ++k)
+                std::memcpy(digests + 20ull * mine[k], local.data() + 20 * k, 20);
+            shard_ms[static_cast<size_t>(d)] = snappy_profile_last_ms(0);
+            return SNAPPY_OK;
         });
-    }
+    };
+    std::vector<std::thread> workers;
+    std::vector<int> inline_shards;  // no thread to be had: the calling thread takes them afterwards
+    for (int d = 1; d < shards; ++d)
+        if (!try_spawn(workers, [&run_shard, d] { run_shard(d); }))
+            inline_shards.push_back(d);
+    run_shard(0);
+    for (int d : inline_shards)
+        run_shard(d);
     for (auto &w : workers)
         w.join();
+    // The call's kernel time is that of its slowest device.
+    profile_reset();
+    float slowest = -1.f;
+    for (float ms : shard_ms)
+        slowest = std::max(slowest, ms);
+    if (slowest >= 0.f)
+        profile_store(0, slowest);
     for (int v : status)
         if (v != SNAPPY_OK)
             return v;
@@ -450,127 +532,168 @@ using namespace snappy;
 extern "C" int snappy_plan_shards(const uint64_t *lengths, uint64_t n, uint32_t n_shards,
                                   uint64_t *cuts)
 {
-    if ((n && !lengths) || !cuts || n_shards == 0)
-        return SNAPPY_E_INVALID_ARG;
-    plan_shards(lengths, n, n_shards, cuts);
-    return SNAPPY_OK;
+    return abi_guard([&]() -> int {
+        if ((n && !lengths) || !cuts || n_shards == 0)
+            return SNAPPY_E_INVALID_ARG;
+        plan_shards(lengths, n, n_shards, cuts);
+        return SNAPPY_OK;
+    });
+}
+
+extern "C" int snappy_plan_shards_lpt(const uint64_t *lengths, uint64_t n, uint32_t n_shards,
+                                      uint32_t *shard_of, uint64_t *shard_blocks)
+{
+    return abi_guard([&]() -> int {
+        if ((n && (!lengths || !shard_of)) || n_shards == 0)
+            return SNAPPY_E_INVALID_ARG;
+        plan_shards_lpt(lengths, n, n_shards, shard_of, shard_blocks);
+        return SNAPPY_OK;
+    });
+}
+
+extern "C" int snappy_device_work(int device, uint64_t *units, uint64_t *bytes)
+{
+    return abi_guard([&]() -> int {
+        DeviceCtx *dev = bound_device(device);
+        if (!dev || !units || !bytes)
+            return SNAPPY_E_INVALID_ARG;
+        *units = dev->work_units.load();
+        *bytes = dev->work_bytes.load();
+        return SNAPPY_OK;
+    });
 }
 
 extern "C" int snappy_sha1(const uint8_t *data, uint64_t len, uint8_t out20[20])
 {
-    if (!out20 || (!data && len))
-        return SNAPPY_E_INVALID_ARG;
-    std::vector<HostRange> r{{data, len}};
-    return hash_ranges(r, out20);
+    return abi_guard([&]() -> int {
+        if (!out20 || (!data && len))
+            return SNAPPY_E_INVALID_ARG;
+        std::vector<HostRange> r{{data, len}};
+        return hash_ranges(r, out20);
+    });
 }
 
 extern "C" int snappy_digests_to_hex(const uint8_t *digests, uint64_t n, char *hex)
 {
-    if ((!digests || !hex) && n)
-        return SNAPPY_E_INVALID_ARG;
-    static const char kDigits[] = "0123456789ABCDEF";  // "X2": uppercase
-    for (uint64_t i = 0; i < n; ++i) {
-        for (int b = 0; b < 20; ++b) {
-            hex[41 * i + 2 * b] = kDigits[digests[20 * i + b] >> 4];
-            hex[41 * i + 2 * b + 1] = kDigits[digests[20 * i + b] & 15];
+    return abi_guard([&]() -> int {
+        if ((!digests || !hex) && n)
+            return SNAPPY_E_INVALID_ARG;
+        static const char kDigits[] = "0123456789ABCDEF";  // "X2": uppercase
+        for (uint64_t i = 0; i < n; ++i) {
+            for (int b = 0; b < 20; ++b) {
+                hex[41 * i + 2 * b] = kDigits[digests[20 * i + b] >> 4];
+                hex[41 * i + 2 * b + 1] = kDigits[digests[20 * i + b] & 15];
+            }
+            hex[41 * i + 40] = '\0';
         }
-        hex[41 * i + 40] = '\0';
-    }
-    return SNAPPY_OK;
+        return SNAPPY_OK;
+    });
 }
 
 extern "C" int snappy_sha1_hex(const uint8_t *data, uint64_t len, char out41[41])
 {
-    if (!out41)
-        return SNAPPY_E_INVALID_ARG;
-    uint8_t d[20];
-    int st = snappy_sha1(data, len, d);
-    if (st != SNAPPY_OK)
-        return st;
-    return snappy_digests_to_hex(d, 1, out41);
+    return abi_guard([&]() -> int {
+        if (!out41)
+            return SNAPPY_E_INVALID_ARG;
+        uint8_t d[20];
+        int st = snappy_sha1(data, len, d);
+        if (st != SNAPPY_OK)
+            return st;
+        return snappy_digests_to_hex(d, 1, out41);
+    });
 }
 
 extern "C" int snappy_sha1_batch(const uint8_t *base, const uint64_t *offsets,
                                  const uint64_t *lengths, uint64_t n, uint8_t *digests)
 {
-    if (n && (!offsets || !lengths || !digests))
-        return SNAPPY_E_INVALID_ARG;
-    std::vector<HostRange> r(n);
-    for (uint64_t i = 0; i < n; ++i) {
-        if (lengths[i] && !base)
+    return abi_guard([&]() -> int {
+        if (n && (!offsets || !lengths || !digests))
             return SNAPPY_E_INVALID_ARG;
-        r[i] = {base ? base + offsets[i] : nullptr, lengths[i]};
-    }
-    return hash_ranges(r, digests);
+        std::vector<HostRange> r(n);
+        for (uint64_t i = 0; i < n; ++i) {
+            if (lengths[i] && !base)
+                return SNAPPY_E_INVALID_ARG;
+            r[i] = {base ? base + offsets[i] : nullptr, lengths[i]};
+        }
+        return hash_ranges(r, digests);
+    });
 }
 
 extern "C" int snappy_sha1_files(const uint8_t *const *datas, const uint64_t *lengths, uint64_t n,
                                  uint8_t *digests)
 {
-    if (n && (!datas || !lengths || !digests))
-        return SNAPPY_E_INVALID_ARG;
-    std::vector<HostRange> r(n);
-    for (uint64_t i = 0; i < n; ++i) {
-        if (lengths[i] && !datas[i])
+    return abi_guard([&]() -> int {
+        if (n && (!datas || !lengths || !digests))
             return SNAPPY_E_INVALID_ARG;
-        r[i] = {datas[i], lengths[i]};
-    }
-    return hash_ranges(r, digests);
+        std::vector<HostRange> r(n);
+        for (uint64_t i = 0; i < n; ++i) {
+            if (lengths[i] && !datas[i])
+                return SNAPPY_E_INVALID_ARG;
+            r[i] = {datas[i], lengths[i]};
+        }
+        return hash_ranges(r, digests);
+    });
 }
 
 extern "C" int snappy_sha1_batch_device(int device, const void *d_base, const uint64_t *offsets,
                                         const uint64_t *lengths, uint64_t n, uint8_t *digests,
                                         void *stream)
 {
-    if (n && (!offsets || !lengths || !digests))
-        return SNAPPY_E_INVALID_ARG;
-    if (n >= 0xFFFFFFF0ull)
-        return SNAPPY_E_INVALID_ARG;
-    if (n == 0)
-        return SNAPPY_OK;
-    if (!d_base)
-        for (uint64_t i = 0; i < n; ++i)
-            if (lengths[i])
-                return SNAPPY_E_INVALID_ARG;
-    SlotLease lease;
-    int st = lease.acquire(device);
-    if (st != SNAPPY_OK)
-        return st;
-    profile_reset();
-    return run_sha1_tables(lease, static_cast<const uint8_t *>(d_base), offsets, lengths, n,
-                           digests, static_cast<hipStream_t>(stream));
+    return abi_guard([&]() -> int {
+        if (n && (!offsets || !lengths || !digests))
+            return SNAPPY_E_INVALID_ARG;
+        if (n >= 0xFFFFFFF0ull)
+            return SNAPPY_E_INVALID_ARG;
+        if (n == 0)
+            return SNAPPY_OK;
+        if (!d_base)
+            for (uint64_t i = 0; i < n; ++i)
+                if (lengths[i])
+                    return SNAPPY_E_INVALID_ARG;
+        SlotLease lease;
+        int st = lease.acquire(device);
+        if (st != SNAPPY_OK)
+            return st;
+        profile_reset();
+        return run_sha1_tables(lease, static_cast<const uint8_t *>(d_base), offsets, lengths, n,
+                               digests, static_cast<hipStream_t>(stream));
+    });
 }
 
 extern "C" int snappy_sha1_batch_resident(int device, const void *d_base,
                                           const uint64_t *d_offsets, const uint64_t *d_lengths,
                                           uint64_t n, uint8_t *d_digests, void *stream)
 {
-    if (n && (!d_offsets || !d_lengths || !d_digests))
-        return SNAPPY_E_INVALID_ARG;
-    if (n == 0)
+    return abi_guard([&]() -> int {
+        if (n && (!d_offsets || !d_lengths || !d_digests))
+            return SNAPPY_E_INVALID_ARG;
+        if (n == 0)
+            return SNAPPY_OK;
+        SlotLease lease;
+        int st = lease.acquire(device);
+        if (st != SNAPPY_OK)
+            return st;
+        profile_reset();
+        hipStream_t s = stream ? static_cast<hipStream_t>(stream) : lease.slot->stream;
+        st = enqueue_sha1_resident(lease, static_cast<const uint8_t *>(d_base), d_offsets, d_lengths,
+                                   n, d_digests, s);
+        if (st != SNAPPY_OK)
+            return st;
+        SNAPPY_HIP_TRY(hipStreamSynchronize(s));
+        finish_sha1_profile(lease);
         return SNAPPY_OK;
-    SlotLease lease;
-    int st = lease.acquire(device);
-    if (st != SNAPPY_OK)
-        return st;
-    profile_reset();
-    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : lease.slot->stream;
-    st = enqueue_sha1_resident(lease, static_cast<const uint8_t *>(d_base), d_offsets, d_lengths,
-                               n, d_digests, s);
-    if (st != SNAPPY_OK)
-        return st;
-    SNAPPY_HIP_TRY(hipStreamSynchronize(s));
-    finish_sha1_profile(lease);
-    return SNAPPY_OK;
+    });
 }
 
 extern "C" int snappy_sha1_last_plan(uint32_t path_end[4], double *planned_ms)
 {
-    if (!t_plan_valid || !path_end)
-        return SNAPPY_E_INVALID_ARG;
-    for (int k = 0; k < kSha1Paths; ++k)
-        path_end[k] = t_plan_end[k];
-    if (planned_ms)
-        *planned_ms = t_plan_ms;
-    return SNAPPY_OK;
+    return abi_guard([&]() -> int {
+        if (!t_plan_valid || !path_end)
+            return SNAPPY_E_INVALID_ARG;
+        for (int k = 0; k < kSha1Paths; ++k)
+            path_end[k] = t_plan_end[k];
+        if (planned_ms)
+            *planned_ms = t_plan_ms;
+        return SNAPPY_OK;
+    });
 }

@@ -49,4 +49,9 @@ int sha1_batch_gated(const uint8_t *base, const uint64_t *offsets, const uint64_
 // (cuts has n_shards + 1 entries).
 void plan_shards(const uint64_t *lengths, uint64_t n, uint32_t n_shards, uint64_t *cuts);
 
+// The same by longest-processing-time-first over padded 64-byte blocks: shard_of[i]
+// is the shard of file i, shard_blocks (may be null) the blocks each shard ends with.
+void plan_shards_lpt(const uint64_t *lengths, uint64_t n, uint32_t n_shards, uint32_t *shard_of,
+                     uint64_t *shard_blocks);
+
 }  // namespace snappy

@@ -63,48 +63,50 @@ extern "C" int snappy_sha1_batch_resident_noalloc(int device, const void *d_base
                                                   const uint64_t *d_lengths, uint64_t n,
                                                   uint8_t *d_digests, void *stream)
 {
-    if (n && (!d_offsets || !d_lengths || !d_digests))
-        return SNAPPY_E_INVALID_ARG;
-    if (n > kNoAllocMaxFiles) {
-        char msg[160];
-        std::snprintf(msg, sizeof msg,
-                      "snappy_sha1_batch_resident_noalloc takes at most %llu files per call, got %llu",
-                      static_cast<unsigned long long>(kNoAllocMaxFiles),
-                      static_cast<unsigned long long>(n));
-        set_error_detail(msg);
-        return SNAPPY_E_CAPACITY;
-    }
-    // Initialisation creates host-side tables: it is the caller's job (snappy_init),
-    // not something this entry point does on the side.
-    DeviceCtx *dev = bound_device(device);
-    if (dev == nullptr) {
-        set_error_detail("snappy_init has not run, or the device index is out of range");
-        return snappy_device_count() == 0 ? SNAPPY_E_NO_DEVICE : SNAPPY_E_INVALID_ARG;
-    }
-    if (n == 0)
+    return abi_guard([&]() -> int {
+        if (n && (!d_offsets || !d_lengths || !d_digests))
+            return SNAPPY_E_INVALID_ARG;
+        if (n > kNoAllocMaxFiles) {
+            char msg[160];
+            std::snprintf(msg, sizeof msg,
+                          "snappy_sha1_batch_resident_noalloc takes at most %llu files per call, got %llu",
+                          static_cast<unsigned long long>(kNoAllocMaxFiles),
+                          static_cast<unsigned long long>(n));
+            set_error_detail(msg);
+            return SNAPPY_E_CAPACITY;
+        }
+        // Initialisation creates host-side tables: it is the caller's job (snappy_init),
+        // not something this entry point does on the side.
+        DeviceCtx *dev = bound_device(device);
+        if (dev == nullptr) {
+            set_error_detail("snappy_init has not run, or the device index is out of range");
+            return snappy_device_count() == 0 ? SNAPPY_E_NO_DEVICE : SNAPPY_E_INVALID_ARG;
+        }
+        if (n == 0)
+            return SNAPPY_OK;
+        const int hip_device = dev->hip_device;
+        if (hip_device < 0 || hip_device >= kMaxHipDevices || g_scratch_ptr[hip_device] == nullptr) {
+            set_error_detail("the planning area of this device was not set up");
+            return SNAPPY_E_HIP;
+        }
+        SNAPPY_HIP_TRY(hipSetDevice(hip_device));
+
+        unsigned char *area = g_scratch_ptr[hip_device];
+        Sha1PlanState *d_state = reinterpret_cast<Sha1PlanState *>(area);
+        Sha1Task *d_tasks = reinterpret_cast<Sha1Task *>(area + kStateBytes);
+        hipStream_t s = static_cast<hipStream_t>(stream);  // null: the device's default stream
+        const uint32_t n32 = static_cast<uint32_t>(n);
+        const uint32_t n_simd = 4u * static_cast<uint32_t>(dev->n_cu);
+        const Sha1CostModel model = sha1_cost_model(n_simd, false);
+
+        std::lock_guard<std::mutex> turn(g_scratch_mu[hip_device]);
+        // The planner clears its header itself (the array still holds the last call's);
+        // the task list is rewritten for entries [0, n) and read no further.
+        SNAPPY_HIP_TRY(launch_sha1_plan(d_offsets, d_lengths, nullptr, n32, d_state, d_tasks, model, s));
+        const int launch_rounds = (n >= 128ull * n_simd) ? kMaxWavesPerSimd : 1;
+        SNAPPY_HIP_TRY(launch_sha1_hop(static_cast<const uint8_t *>(d_base), d_tasks, d_state, d_digests,
+                                       nullptr, n32, n_simd, launch_rounds, s));
+        SNAPPY_HIP_TRY(hipStreamSynchronize(s));
         return SNAPPY_OK;
-    const int hip_device = dev->hip_device;
-    if (hip_device < 0 || hip_device >= kMaxHipDevices || g_scratch_ptr[hip_device] == nullptr) {
-        set_error_detail("the planning area of this device was not set up");
-        return SNAPPY_E_HIP;
-    }
-    SNAPPY_HIP_TRY(hipSetDevice(hip_device));
-
-    unsigned char *area = g_scratch_ptr[hip_device];
-    Sha1PlanState *d_state = reinterpret_cast<Sha1PlanState *>(area);
-    Sha1Task *d_tasks = reinterpret_cast<Sha1Task *>(area + kStateBytes);
-    hipStream_t s = static_cast<hipStream_t>(stream);  // null: the device's default stream
-    const uint32_t n32 = static_cast<uint32_t>(n);
-    const uint32_t n_simd = 4u * static_cast<uint32_t>(dev->n_cu);
-    const Sha1CostModel model = sha1_cost_model(n_simd, false);
-
-    std::lock_guard<std::mutex> turn(g_scratch_mu[hip_device]);
-    // The planner clears its header itself (the array still holds the last call's);
-    // the task list is rewritten for entries [0, n) and read no further.
-    SNAPPY_HIP_TRY(launch_sha1_plan(d_offsets, d_lengths, nullptr, n32, d_state, d_tasks, model, s));
-    const int launch_rounds = (n >= 128ull * n_simd) ? kMaxWavesPerSimd : 1;
-    SNAPPY_HIP_TRY(launch_sha1_hop(static_cast<const uint8_t *>(d_base), d_tasks, d_state, d_digests,
-                                   nullptr, n32, n_simd, launch_rounds, s));
-    SNAPPY_HIP_TRY(hipStreamSynchronize(s));
-    return SNAPPY_OK;
+    });
 }

@@ -139,8 +139,15 @@ hipError_t transfer_staged(Slot &s, int hip_device, const std::vector<Piece> &pi
     const unsigned n_threads = static_cast<unsigned>(std::min<uint64_t>(
         n_slices, std::min<unsigned>(kStageThreads, std::max(1u, std::thread::hardware_concurrency()))));
     std::vector<std::thread> workers;
+    workers.reserve(n_threads);
     for (unsigned t = 0; t < n_threads; ++t)
-        workers.emplace_back(fill);
+        if (!try_spawn(workers, fill))
+            break;
+    if (workers.empty()) {
+        for (unsigned r = 0; r < ring_slots; ++r)
+            (void)hipEventDestroy(sent[r]);
+        return hipErrorOutOfMemory;  // not one thread to stage with
+    }
 
     hipError_t e = hipSuccess;
     for (uint64_t k = 0; k < n_slices && e == hipSuccess; ++k) {
@@ -278,8 +285,15 @@ hipError_t transfer_to_host(Slot &s, int hip_device, const uint8_t *d_src, uint8
     const unsigned n_threads = static_cast<unsigned>(std::min<uint64_t>(
         n_slices, std::min<unsigned>(kStageThreads, std::max(1u, std::thread::hardware_concurrency()))));
     std::vector<std::thread> workers;
+    workers.reserve(n_threads);
     for (unsigned t = 0; t < n_threads; ++t)
-        workers.emplace_back(drain);
+        if (!try_spawn(workers, drain))
+            break;
+    if (workers.empty()) {
+        for (unsigned r = 0; r < ring_slots; ++r)
+            (void)hipEventDestroy(landed[r]);
+        return hipErrorOutOfMemory;  // not one thread to drain with
+    }
 
     hipError_t e = hipSuccess;
     for (uint64_t k = 0; k < n_slices && e == hipSuccess; ++k) {

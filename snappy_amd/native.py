@@ -27,6 +27,8 @@ E_MCDF_MAGIC = -20
 E_MCDF_VERSION = -21
 E_MCDF_TRUNCATED = -22
 E_MCDF_JSON = -23
+E_MCDF_BASE64 = -24
+E_SNAPSHOT_JSON = -30
 
 FILE_HASHED = 0
 FILE_SKIPPED_EMPTY = 1
@@ -51,6 +53,8 @@ SYMBOLS = [
     ("snappy_sha1_batch_device", _i, [_i, _vp, _vp, _vp, _u64, _vp, _vp]),
     ("snappy_sha1_batch_resident", _i, [_i, _vp, _vp, _vp, _u64, _vp, _vp]),
     ("snappy_sha1_batch_resident_noalloc", _i, [_i, _vp, _vp, _vp, _u64, _vp, _vp]),
+    ("snappy_plan_shards_lpt", _i, [_vp, _u64, ctypes.c_uint32, _vp, _vp]),
+    ("snappy_device_work", _i, [_i, _u64p, _u64p]),
     ("snappy_plan_shards", _i, [_vp, _u64, ctypes.c_uint32, _vp]),
     ("snappy_lz4net_decoded_size", _i, [_vp, _u64, _u64p]),
     ("snappy_lz4net_decode", _i, [_vp, _u64, _vp, _u64, _u64p]),
@@ -58,6 +62,8 @@ SYMBOLS = [
     ("snappy_mcdf_decode_and_hash", _i, [_vp, _u64, _vp, _vp, _u64, _u64p, _u64p, _vp, _u64, _u64p]),
     ("snappy_mcdf_decode_and_hash_batch", _i, [_u64, _vp, _vp, _vp, _vp, _u64, _vp, _vp, _vp, _vp]),
     ("snappy_store_files", _i, [_vp, _u64, ctypes.c_char_p, _vp, _vp]),
+    ("snappy_update_snapshot", _i, [ctypes.c_char_p, ctypes.c_char_p, _vp, _vp, _vp, _u64, ctypes.c_char_p,
+                                    ctypes.c_char_p, ctypes.c_char_p, _vp, _vp]),
     ("snappy_mcdf_import_to_dir", _i, [ctypes.c_char_p, ctypes.c_char_p, _vp, _u64]),
     ("snappy_mcdf_write_header", _i, [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p,
                                       _vp, _vp, _vp, _u64, _vp, _u64, _u64p]),

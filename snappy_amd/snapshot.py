@@ -27,6 +27,24 @@ def store_files(paths, files_dir=None):
     return [raw[41 * i: 41 * i + 40].decode("ascii") if status[i] == 0 else None for i in range(n)]
 
 
+def update_snapshot(snapshot_dir, source_actor, replacements, glamourer="", customize="", manipulation=""):
+    """UpdateSnapshot for the local player: replacements = [(resolved_path, [game paths])].
+    Returns a list with each file's HASH, or None where the resolved path names no file."""
+    n = len(replacements)
+    res = (ctypes.c_char_p * max(n, 1))(*[os.fsencode(r) for r, _ in replacements])
+    flat = [g.encode("utf-8") for _, paths in replacements for g in paths]
+    gps = (ctypes.c_char_p * max(len(flat), 1))(*flat)
+    per = np.array([len(paths) for _, paths in replacements], dtype=np.uint32)
+    hexbuf = ctypes.create_string_buffer(41 * max(n, 1))
+    status = np.zeros(max(n, 1), dtype=np.uint8)
+    native.check(native.lib().snappy_update_snapshot(
+        os.fsencode(snapshot_dir), source_actor.encode("utf-8"), res, gps, per.ctypes.data, n,
+        glamourer.encode("utf-8"), customize.encode("utf-8"), manipulation.encode("utf-8"),
+        hexbuf, status.ctypes.data), "snappy_update_snapshot")
+    raw = hexbuf.raw
+    return [raw[41 * i: 41 * i + 40].decode("ascii") if status[i] == 0 else None for i in range(n)]
+
+
 def import_mcdf(mcdf_path, working_dir) -> str:
     """ImportMcdf: writes the snapshot folder and returns its path."""
     out = ctypes.create_string_buffer(4096)

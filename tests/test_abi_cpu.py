@@ -161,3 +161,141 @@ def test_mcdf_write_header_is_compact_json_in_declaration_order(snappy, oracle):
     assert parsed["Files"] == [(p, ln) for p, ln in files]
     empty = snappy.mcdf_write_header([])
     assert empty[9:] == b'{"Description":"","GlamourerData":"","CustomizePlusData":"","ManipulationData":"","Files":[]}'
+
+
+def test_hostile_sizes_return_a_status(snappy):
+    """Nothing may unwind through the C ABI: a header that would blow up the JSON reader and a
+    file count no container can hold both come back as status codes."""
+    import struct
+
+    n = snappy.native
+    js = b"[" + b"[]," * 3_000_000 + b"[]]"                 # ~9 MB of text, 3 million values
+    payload = b"MCDF\x01" + struct.pack("<i", len(js)) + js
+    with pytest.raises(n.SnappyError) as e:
+        snappy.mcdf_parse_header(payload)
+    assert e.value.code == n.E_MCDF_JSON
+    deep = b"[" * 100_000
+    with pytest.raises(n.SnappyError) as e:
+        snappy.mcdf_parse_header(b"MCDF\x01" + struct.pack("<i", len(deep)) + deep)
+    assert e.value.code == n.E_MCDF_JSON
+    L = n.lib()
+    one = np.zeros(1, dtype=np.uint64)
+    out = np.zeros(20, dtype=np.uint8)
+    for absurd in (1 << 62, (1 << 64) - 1):
+        st = L.snappy_sha1_batch(out.ctypes.data, one.ctypes.data, one.ctypes.data, absurd, out.ctypes.data)
+        assert st in (n.E_NOMEM, n.E_INVALID_ARG), st
+        st = L.snappy_sha1_files(one.ctypes.data, one.ctypes.data, absurd, out.ctypes.data)
+        assert st in (n.E_NOMEM, n.E_INVALID_ARG), st
+
+
+def _lpt_restated(lengths, k):
+    """snappy_plan_shards_lpt in plain Python."""
+    blocks = [(int(v) + 8) // 64 + 1 for v in lengths]
+    total = sum(blocks)
+    average = -(-total // k)
+    large_from = max(1, average // 64)
+    load = [0] * k
+    shard_of = [0] * len(blocks)
+    large = sorted((i for i, b in enumerate(blocks) if b >= large_from), key=lambda i: -blocks[i])
+    for i in large:
+        d = load.index(min(load))
+        shard_of[i] = d
+        load[d] += blocks[i]
+    d = 0
+    for i, b in enumerate(blocks):
+        if b >= large_from:
+            continue
+        while d + 1 < k and load[d] >= average:
+            d += 1
+        shard_of[i] = d
+        load[d] += b
+    return shard_of, load
+
+
+def test_plan_shards_lpt_properties(snappy):
+    from snappy_amd.crypto import plan_shards_lpt
+
+    rng = np.random.default_rng(18)
+    cases = [(0, 3), (1, 4), (5, 5), (37, 2), (1000, 8), (20000, 8)]
+    for n, k in cases:
+        if n == 20000:      # the small-file regime: nothing is "large", runs stay contiguous
+            ln = rng.integers(4096, 32769, size=n).astype(np.uint64)
+        else:
+            ln = np.exp(rng.uniform(np.log(1), np.log(22 << 20), size=n)).astype(np.uint64)
+        shard_of, blocks = plan_shards_lpt(ln, k)
+        want_of, want_blocks = _lpt_restated(ln, k)
+        assert list(shard_of) == want_of and list(blocks) == want_blocks
+        per_file = (ln + 8) // 64 + 1
+        assert int(blocks.sum()) == int(per_file.sum())
+        if n >= 1000:
+            # longest-first: no shard above the average by more than the largest file
+            assert int(blocks.max()) <= int(per_file.sum()) // k + int(per_file.max())
+        if n == 20000:
+            assert np.all(np.diff(shard_of.astype(np.int64)) >= 0)      # contiguous runs in caller order
+            assert int(blocks.max()) - int(blocks.min()) <= 2 * int(per_file.max()) + int(per_file.sum()) // (64 * k)
+    # the full-size asset corpus: 100 GB, 70 % .tex-like bytes, 30 % .mdl-like, over 8 devices
+    import sys
+
+    sys.path.insert(0, H.ROOT)
+    import bench
+
+    ln = bench.make_sizes("corpus", np.random.default_rng(0x534E4150), 1.0)
+    shard_of, blocks = plan_shards_lpt(ln, 8)
+    assert blocks.max() / blocks.mean() < 1.001
+    assert len(set(shard_of.tolist())) == 8
+
+
+def test_integration_text_matches_the_library(snappy):
+    """The P/Invoke declarations a maintainer would paste against the header and the
+    ctypes table: same names, same number of arguments, pointers where the C side has pointers,
+    integers of the same width."""
+    text = open(os.path.join(H.ROOT, "INTEGRATION.md")).read()
+    decls = re.findall(r"\[LibraryImport\([^\]]*\)\]\s*internal static partial\s+(\w+)\s+(snappy_\w+)\s*\(([^;]*?)\);",
+                       text, flags=re.S)
+    assert len(decls) >= 25
+    header = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    protos = {m[1]: (m[0], m[2]) for m in re.findall(
+        r"^\s*((?:const\s+)?[A-Za-z_0-9]+\s*\*?)\s*(snappy_\w+)\s*\(([^;]*?)\)\s*;", header, flags=re.S | re.M)}
+    table = {name: (restype, argtypes) for name, restype, argtypes in snappy.native.SYMBOLS}
+
+    scalars = {"uint64_t": "u64", "int64_t": "i64", "uint32_t": "u32", "int": "i32", "float": "f32",
+               "double": "f64", "uint8_t": "u8", "char": "u8", "void": "void"}
+
+    def c_kind(param):
+        words = param.replace("const", " ").replace("*", " * ").split()
+        stars = words.count("*") + (1 if "[" in param else 0)
+        base = scalars[words[0]]
+        if stars == 0:
+            return base
+        return "ptr:ptr" if stars > 1 else "ptr:" + base
+
+    def cs_kind(param):
+        t = param.strip().rsplit(None, 1)[0]
+        if t in ("string", "IntPtr"):
+            return "ptr:u8"
+        if t == "string[]" or t.endswith("**"):
+            return "ptr:ptr"
+        base = {"ulong": "u64", "long": "i64", "uint": "u32", "int": "i32", "float": "f32", "double": "f64",
+                "byte": "u8", "void": "void"}[t.rstrip("*")]
+        return "ptr:" + base if t.endswith("*") else base
+
+    def ct_kind(t):      # the ctypes table only tells pointers from integers
+        if t in (ctypes.c_void_p, ctypes.c_char_p) or hasattr(t, "contents"):
+            return "ptr"
+        return {ctypes.c_uint64: "u64", ctypes.c_int64: "i64", ctypes.c_uint32: "u32", ctypes.c_int: "i32",
+                ctypes.c_float: "f32"}[t]
+
+    seen = set()
+    for ret, name, params in decls:
+        assert name in protos, f"{name} is bound in INTEGRATION.md but not declared in the header"
+        c_params = [p for p in protos[name][1].split(",") if p.strip() and p.strip() != "void"]
+        cs_params = [p for p in params.split(",") if p.strip()]
+        assert len(cs_params) == len(c_params), name
+        assert [cs_kind(p) for p in cs_params] == [c_kind(p) for p in c_params], name
+        assert [ct_kind(t) for t in table[name][1]] == [c_kind(p).split(":")[0] for p in c_params], name
+        c_ret = protos[name][0].strip()
+        want_ret = {"int": "int", "void": "void", "float": "float", "const char *": "IntPtr"}[c_ret]
+        assert ret == want_ret, name
+        seen.add(name)
+    # every entry point of the header has a binding in the text
+    assert seen == set(protos), set(protos) ^ seen

@@ -163,3 +163,131 @@ def test_store_files_reads_while_hashing(snappy, tmp_path):
         else:
             assert g == w, i
             assert (files_dir / f"{w}.dat").stat().st_size == os.path.getsize(paths[i])
+
+
+@pytest.mark.parametrize("name", ["..", ".", "/tmp/snappy_escape_test", "a/b", "a\\b", "   "])
+def test_import_mcdf_refuses_folder_names_that_leave_the_working_dir(snappy, oracle, tmp_path, name):
+    """The Description names the folder that is deleted and recreated; it comes out of a file
+    made by someone else.  Anything but a single path component is refused before the file
+    system is touched (the reference would hand it to Directory.Delete as it is)."""
+    work = tmp_path / "outer" / "snapshots"
+    work.mkdir(parents=True)
+    (tmp_path / "outer" / "neighbour.txt").write_text("keep")
+    (work / "existing").mkdir()
+    (work / "existing" / "f.txt").write_text("keep")
+    payload = oracle.build_mcdf_payload(name, [(["chara/x.tex"], b"abcdef", 6)])
+    mcdf = tmp_path / "evil.mcdf"
+    mcdf.write_bytes(oracle.lz4net_encode(payload, chunk_size=4096))
+    before = sorted(str(p.relative_to(tmp_path)) for p in tmp_path.rglob("*"))
+    with pytest.raises(snappy.native.SnappyError) as e:
+        snappy.import_mcdf(str(mcdf), str(work))
+    assert e.value.code == snappy.native.E_INVALID_ARG
+    assert sorted(str(p.relative_to(tmp_path)) for p in tmp_path.rglob("*")) == before
+    assert not os.path.exists("/tmp/snappy_escape_test")
+
+
+def test_import_mcdf_customize_data_and_escapes(snappy, oracle, tmp_path):
+    """CustomizePlusData must be Base64 (Convert.FromBase64String throws after the files have been
+    extracted, before anything is saved); JsonConvert escapes U+0085, U+2028 and U+2029."""
+    import base64
+
+    files = [(["chara/x.tex"], b"abcdef", 6)]
+    work = tmp_path / "w"
+    bad = oracle.build_mcdf_payload("bad64", files, extra={"CustomizePlusData": "not*base64"})
+    p = tmp_path / "bad64.mcdf"
+    p.write_bytes(oracle.lz4net_encode(bad, chunk_size=4096))
+    with pytest.raises(snappy.native.SnappyError) as e:
+        snappy.import_mcdf(str(p), str(work))
+    assert e.value.code == snappy.native.E_MCDF_BASE64
+    assert os.listdir(work / "bad64" / "_files") and not (work / "bad64" / "snapshot.json").exists()
+    for wrong in ("QUJD=", "QUJ=Q", "QQ=", "Q==="):
+        q = tmp_path / "w2.mcdf"
+        q.write_bytes(oracle.lz4net_encode(oracle.build_mcdf_payload("w2", files, extra={"CustomizePlusData": wrong}),
+                                           chunk_size=4096))
+        with pytest.raises(snappy.native.SnappyError) as e:
+            snappy.import_mcdf(str(q), str(work))
+        assert e.value.code == snappy.native.E_MCDF_BASE64, wrong
+    profile = base64.b64encode(b'{"Bones":{}}').decode()
+    spaced = profile[:4] + " \r\n" + profile[4:]          # white space is ignored by the managed decoder
+    manip = "line\u2028sep para\u2029graph nel\u0085."
+    good = oracle.build_mcdf_payload("ok64", files, extra={"CustomizePlusData": spaced, "ManipulationData": manip})
+    g = tmp_path / "ok64.mcdf"
+    g.write_bytes(oracle.lz4net_encode(good, chunk_size=4096))
+    out = snappy.import_mcdf(str(g), str(work))
+    cust = json.load(open(os.path.join(out, "customize_history.json")))
+    assert cust["Entries"][0]["CustomizeData"] == spaced and cust["Entries"][0]["CustomizeTemplate"] == ""
+    assert list(cust["Entries"][0]) == ["Timestamp", "Description", "CustomizeData", "CustomizeTemplate"]
+    text = open(os.path.join(out, "snapshot.json"), encoding="utf-8").read()
+    assert "\\u2028" in text and "\\u2029" in text and "\\u0085" in text
+    assert "\u2028" not in text and "\u2029" not in text and "\u0085" not in text
+    assert json.loads(text)["ManipulationString"] == manip
+
+
+def _folder_state(path):
+    """Everything UpdateSnapshot leaves in a snapshot folder, with the time stamps blanked."""
+    import re
+
+    files = {name: open(os.path.join(path, "_files", name), "rb").read()
+             for name in sorted(os.listdir(os.path.join(path, "_files")))}
+    docs = {}
+    for name in ("snapshot.json", "glamourer_history.json", "customize_history.json"):
+        text = open(os.path.join(path, name), encoding="utf-8").read()
+        text = re.sub(r"\d{4}-\d\d-\d\dT\d\d:\d\d:\d\d\.\d{7}Z", "<now>", text)
+        text = re.sub(r"Update - \d{4}-\d\d-\d\d \d\d:\d\d:\d\d UTC", "Update - <now> UTC", text)
+        docs[name] = text
+    return sorted(os.listdir(path)), files, docs
+
+
+def test_update_snapshot_matches_the_reference_loop(snappy, oracle, tmp_path):
+    """Save, then save again over the same folder: the folder the library leaves must equal,
+    file for file and byte for byte (time stamps aside), the one the oracle's sequential
+    restatement of BuildSnapshotFromLocalPlayer + UpdateSnapshot leaves."""
+    rng = np.random.default_rng(33)
+    mods = tmp_path / "mods"
+    mods.mkdir()
+    blobs = [H.random_bytes(int(n), 700 + i) for i, n in
+             enumerate([0, 5, 70_000, 1_300_000, 2_000_003, 333, 64, 4_100_000])]
+    blobs[5] = blobs[2]                                   # same content under two resolved paths
+    paths = []
+    for i, b in enumerate(blobs):
+        p = mods / f"m{i}.tex"
+        p.write_bytes(b)
+        paths.append(str(p))
+    first = [(paths[0], ["chara/empty.tex"]),
+             (paths[1], ["chara/a.tex", "chara/A.TEX"]),           # two spellings, one key in snapshot.json
+             (str(mods / "missing.mdl"), ["chara/missing.mdl"]),
+             (paths[2], ["chara/b.tex"]),
+             (paths[3], ["chara/c.tex", 'chara/quo"te.tex']),
+             (paths[5], ["chara/b_copy.tex"]),                     # duplicate content: one .dat
+             (paths[4], ["chara/b.tex"])]                          # same game path again: last hash wins
+    second = [(paths[6], ["CHARA/A.tex"]),                         # folds onto chara/a.tex: spelling kept, hash replaced
+              (paths[7], ["chara/new.mdl"]),
+              (paths[2], ["chara/b.tex"])]
+    ours, theirs = tmp_path / "ours" / "Hero", tmp_path / "theirs" / "Hero"
+    for replacements, glam, cplus, manip in ((first, "glam-1", '{"Bones":{}}', "manip-1"),
+                                            (second, "glam-1", '{"Bones":{"j_kao":{}}}', "manip\u2028two"),
+                                            (second, "glam-3", '{"Bones":{"j_kao":{}}}', "")):
+        got = snappy.update_snapshot(str(ours), "Hero", replacements, glam, cplus, manip)
+        oracle.update_snapshot(str(theirs), "Hero", replacements, glam, cplus, manip)
+        want = [hashlib.sha1(open(r, "rb").read()).hexdigest().upper() if os.path.isfile(r) else None
+                for r, _ in replacements]
+        assert got == want
+        a, b = _folder_state(str(ours)), _folder_state(str(theirs))
+        assert a[0] == b[0]
+        assert a[1] == b[1]
+        for name in a[2]:
+            assert a[2][name] == b[2][name], name
+    info = json.load(open(ours / "snapshot.json"))
+    assert list(info["FileReplacements"])[:2] == ["chara/empty.tex", "chara/a.tex"]
+    assert info["FileReplacements"]["chara/a.tex"] == hashlib.sha1(blobs[6]).hexdigest().upper()
+    assert len(json.load(open(ours / "glamourer_history.json"))["Entries"]) == 2
+    assert len(json.load(open(ours / "customize_history.json"))["Entries"]) == 2
+    # an existing <HASH>.dat is left alone, and a damaged snapshot.json stops the update
+    victim = ours / "_files" / (hashlib.sha1(blobs[7]).hexdigest().upper() + ".dat")
+    victim.write_bytes(b"keep me")
+    snappy.update_snapshot(str(ours), "Hero", second, "glam-3")
+    assert victim.read_bytes() == b"keep me"
+    (ours / "snapshot.json").write_text("{ not json")
+    with pytest.raises(snappy.native.SnappyError) as e:
+        snappy.update_snapshot(str(ours), "Hero", second)
+    assert e.value.code == snappy.native.E_SNAPSHOT_JSON

@@ -338,3 +338,34 @@ def test_concurrent_decoders(snappy, oracle):
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+def test_oversized_claims_do_not_take_the_batch_down(snappy, oracle, monkeypatch):
+    """A chunk header of a dozen bytes may declare 2 GiB of output.  Such an archive is reported
+    on its own (the block cannot decode to that size: corrupt, as the reader would find) and the
+    archives next to it still come back; the same when the device arena cannot hold all of them."""
+    good = [_make_archive(oracle, 8 + k, 70 + k, chunk=1 << 18)[0] for k in range(3)]
+    # 40 compressed bytes that claim 2^31 - 1 decoded bytes
+    bomb = H.varint(1) + H.varint((1 << 31) - 1) + H.varint(40) + bytes(40)
+    st, _ = oracle.lz4net_decode(bomb, out_cap=1 << 20)
+    streams = [good[0], bomb, good[1], good[2]]
+    res = snappy.mcdf_decode_and_hash_batch(streams)
+    assert res[1]["status"] == snappy.native.E_LZ4_CORRUPT
+    for k in (0, 2, 3):
+        ref = oracle.mcdf_import(streams[k])
+        assert res[k]["status"] == 0 and list(res[k]["statuses"]) == ref["statuses"]
+    with pytest.raises(snappy.native.SnappyError) as e:
+        snappy.lz4net_decode(bomb, out_cap=1 << 20)
+    assert e.value.code in (snappy.native.E_LZ4_CORRUPT, snappy.native.E_CAPACITY)
+    # a stream that passes every header check but does not fit next to the others
+    big = oracle.lz4net_encode(oracle.build_mcdf_payload("big", [(["a.tex"], bytes(24 << 20), 24 << 20)]),
+                               chunk_size=1 << 20)
+    monkeypatch.setenv("SNAPPY_TEST_ARENA_LIMIT_BYTES", str(16 << 20))
+    res = snappy.mcdf_decode_and_hash_batch([good[0], big, good[1]])
+    monkeypatch.delenv("SNAPPY_TEST_ARENA_LIMIT_BYTES")
+    assert res[1]["status"] == snappy.native.E_NOMEM
+    assert res[0]["status"] == 0 and res[2]["status"] == 0
+    whole = snappy.mcdf_decode_and_hash_batch([good[0], big, good[1]])
+    assert [r["status"] for r in whole] == [0, 0, 0]
+    assert np.array_equal(whole[0]["digests"], res[0]["digests"])
+    assert np.array_equal(whole[2]["digests"], res[2]["digests"])
