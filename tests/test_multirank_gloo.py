@@ -16,16 +16,17 @@ def test_bench_two_ranks_gloo(tmp_path):
     env.setdefault("MASTER_ADDR", "127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", "29731", os.path.join(H.ROOT, "bench.py"),
-           "--gpus", "2", "--steps", "2", "--warmup", "0", "--cpu-dry-run"]
+           "--gpus", "2", "--steps", "2", "--warmup", "0", "--cpu-dry-run", "--workload", "folder"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env, cwd=H.ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out.stdout          # rank 0 only
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["dry_run"] is True
-    # both ranks' bytes were summed: each corpus is ~16 MB at this scale
+    # both ranks' bytes were summed: each rank has a folder of its own at this scale
     single = subprocess.run([sys.executable, os.path.join(H.ROOT, "bench.py"), "--steps", "1", "--warmup", "0",
-                             "--cpu-dry-run"], capture_output=True, text=True, timeout=240, cwd=H.ROOT)
+                             "--cpu-dry-run", "--workload", "folder"], capture_output=True, text=True, timeout=240,
+                            cwd=H.ROOT)
     assert single.returncode == 0, single.stderr[-2000:]
     one = json.loads([ln for ln in single.stdout.splitlines() if ln.startswith("{")][0])
     assert one["n_gpus"] == 1
@@ -33,31 +34,33 @@ def test_bench_two_ranks_gloo(tmp_path):
     assert one["digest0"] == d["digest0"]         # rank 0 hashes the same corpus either way
 
 
-def test_bench_two_ranks_strong_scaling(tmp_path):
-    """--strong: one corpus for the job, sharded by file; the ranks' bytes add up to it."""
+def test_bench_two_ranks_one_corpus(tmp_path):
+    """The default workload: ONE corpus for the job whatever the number of ranks, dealt out by file
+    (longest first by padded blocks); the ranks' bytes and files add up to it."""
     def run(n):
         cmd = [sys.executable, os.path.join(H.ROOT, "bench.py")]
         if n > 1:
             cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
                    "--master-addr", "127.0.0.1", "--master-port", "29751", os.path.join(H.ROOT, "bench.py")]
-        cmd += ["--gpus", str(n), "--steps", "1", "--warmup", "0", "--cpu-dry-run", "--strong",
-                "--workload", "corpus", "--scale", "0.2"]
+        cmd += ["--gpus", str(n), "--steps", "1", "--warmup", "0", "--cpu-dry-run", "--scale", "2"]
         out = subprocess.run(cmd, capture_output=True, text=True, timeout=240, cwd=H.ROOT)
         assert out.returncode == 0, out.stderr[-2000:]
         return json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
 
     one, two = run(1), run(2)
-    assert two["scaling"] == "strong" and one["scaling"] == "weak"
-    assert two["job_bytes"] == one["job_bytes"]
-    assert two["digest0"] == one["digest0"]           # rank 0's shard starts with the corpus' first file
+    assert two["scaling"] == "strong" and one["scaling"] == "strong"
+    assert two["job_bytes"] == one["job_bytes"] == one["corpus_bytes"] == two["corpus_bytes"]
+    assert two["job_files"] == one["job_files"] == one["files_rank0"]
     assert 0 < two["files_rank0"] < one["files_rank0"]
+    # balance by blocks: rank 0 holds half the bytes, give or take its largest file
+    assert abs(two["bytes_rank0"] - one["job_bytes"] / 2) <= one["largest_rank0"]
 
 
 def _worker(rank, world, port, lengths, seed, ret):
     import torch.distributed as dist
 
     from oracle import oracle
-    from snappy_amd.crypto import plan_shards
+    from snappy_amd.crypto import plan_shards_lpt
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -65,11 +68,11 @@ def _worker(rank, world, port, lengths, seed, ret):
     lengths = np.asarray(lengths, dtype=np.uint64)
     offsets = np.concatenate([[0], np.cumsum(lengths)[:-1]]).astype(np.uint64)
     base = np.random.default_rng(seed).integers(0, 256, size=int(lengths.sum()) + 1, dtype=np.uint8)
-    cuts = plan_shards(lengths, world)            # the library's own split, one shard per rank
-    lo, hi = int(cuts[rank]), int(cuts[rank + 1])
-    mine = oracle.sha1_batch_np(base, offsets[lo:hi], lengths[lo:hi])
+    shard_of, _ = plan_shards_lpt(lengths, world)  # the library's own dealing, one shard per rank
+    idx = np.flatnonzero(shard_of == rank)
+    mine = oracle.sha1_batch_np(base, offsets[idx], lengths[idx])
     gathered = [None] * world
-    dist.all_gather_object(gathered, (lo, hi, mine.tobytes()))   # host-side concatenation, no reduction
+    dist.all_gather_object(gathered, (idx.tolist(), mine.tobytes()))   # host-side merge, no reduction
     if rank == 0:
         ret.put(gathered)
     dist.barrier()
@@ -90,15 +93,18 @@ def test_sharded_file_list_two_ranks(oracle, snappy):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    # coverage: the shards tile the list exactly once, in order
-    assert gathered[0][0] == 0 and gathered[0][1] == gathered[1][0] and gathered[1][1] == len(lengths)
-    merged = b"".join(g[2] for g in gathered)
+    # coverage: every file is in exactly one shard
+    all_idx = sorted(i for g in gathered for i in g[0])
+    assert all_idx == list(range(len(lengths)))
     offsets = np.concatenate([[0], np.cumsum(lengths)[:-1]]).astype(np.uint64)
     base = np.random.default_rng(99).integers(0, 256, size=int(lengths.sum()) + 1, dtype=np.uint8)
     want = oracle.sha1_batch_np(base, offsets, lengths.astype(np.uint64))
-    assert merged == want.tobytes()
+    merged = np.zeros_like(want)
+    for idx, raw in gathered:
+        merged[idx] = np.frombuffer(raw, dtype=np.uint8).reshape(-1, 20)
+    assert np.array_equal(merged, want)
     # balance: neither shard holds more than ~the largest file above half the bytes
-    b0 = int(lengths[: gathered[0][1]].sum())
+    b0 = int(lengths[gathered[0][0]].sum())
     assert abs(b0 - lengths.sum() / 2) <= lengths.max()
 
 

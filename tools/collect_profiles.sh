@@ -25,15 +25,20 @@ run() {  # name, seconds, rocprofv3 options..., --, program...
 quick="--no-extra --no-e2e --no-cpu-baseline --steps 2 --warmup 1"
 
 run trace_default 600 --kernel-trace --stats -- python3 bench.py
-for w in blobs small; do
+for w in corpus blobs small; do
     run pmc_${w}_fetch 300 --pmc FETCH_SIZE GRBM_GUI_ACTIVE -- python3 bench.py --workload $w $quick
     run pmc_${w}_write 300 --pmc WRITE_SIZE -- python3 bench.py --workload $w $quick
     run pmc_${w}_sq 300 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY -- python3 bench.py --workload $w $quick
 done
 run pmc_mcdf_fetch 300 --pmc FETCH_SIZE GRBM_GUI_ACTIVE -- python3 bench.py --workload mcdf --archives 8 --archive-mib 256 --steps 2 --warmup 1
 run pmc_mcdf_write 300 --pmc WRITE_SIZE -- python3 bench.py --workload mcdf --archives 8 --archive-mib 256 --steps 2 --warmup 1
-run trace_corpus 300 --kernel-trace --stats -- python3 bench.py --workload corpus --no-e2e --no-cpu-baseline --steps 2 --warmup 1
+dense="--workload mcdf --mcdf-content dense --archives 8 --archive-mib 256 --steps 2 --warmup 1 --no-cpu-baseline"
+run pmc_dense_fetch 300 --pmc FETCH_SIZE GRBM_GUI_ACTIVE -- python3 bench.py $dense
+run pmc_dense_write 300 --pmc WRITE_SIZE -- python3 bench.py $dense
+run pmc_dense_sq 300 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY -- python3 bench.py $dense
 
 cd "$root"
 python3 tools/rocpd_summary.py $(find "$out" -name "*.db" | sort) > "$out/summary.txt"
+# Only the summary and the logs travel back (the databases are hundreds of MB).
+find "$out" -mindepth 1 -maxdepth 1 -type d -exec rm -rf {} +
 echo done >&2
