@@ -52,6 +52,16 @@ WORKLOAD_TEXT = {
 }
 
 
+def log(text: str):
+    """Progress on stderr (stdout carries the one JSON line)."""
+    if os.environ.get("BENCH_VERBOSE") == "1":
+        print(f"[bench rank {os.environ.get('RANK', '0')} +{time.perf_counter() - _T0:7.1f}s] {text}",
+              file=sys.stderr, flush=True)
+
+
+_T0 = time.perf_counter()
+
+
 def padded_blocks(lengths: np.ndarray) -> np.ndarray:
     return (lengths.astype(np.uint64) + 8) // 64 + 1
 
@@ -608,7 +618,9 @@ def end_to_end(lib, native, torch, holder, offsets, lengths, total_bytes, digest
             dt = float(t.item())
         return dt
 
+    log(f"host copy ready (page-locked: {locked})")
     run(base_address)  # first call sizes the library's device arena
+    log("first end-to-end call done")
     t_host = min(run(base_address) for _ in range(2))
     same = bool(np.array_equal(d2, digests))
     out = {"seconds": t_host, "digests_match_resident_run": same, "page_locked": locked}
@@ -784,8 +796,10 @@ def main():
     offsets = np.concatenate([[0], np.cumsum(lengths)[:-1]]).astype(np.uint64)
     total_bytes = int(lengths.sum())
     algo_bytes = int(padded_blocks(lengths).sum()) * 64
+    log(f"corpus: {len(lengths)} files, {total_bytes} bytes; filling HBM")
     buf = fill_random(torch, total_bytes, device, seed=1234 + rank)
     torch.cuda.synchronize()
+    log("resident data ready")
     n = len(lengths)
     n_cu = torch.cuda.get_device_properties(device).multi_processor_count
 
@@ -795,6 +809,7 @@ def main():
 
     elapsed, kernel_ms, digests = hash_resident(lib, native, torch, device, local_rank, buf, offsets, lengths,
                                                 args.steps, args.warmup, args.workload == "small", barrier)
+    log(f"timed steps done: {elapsed:.3f} s")
     plan = last_plan(lib)
     k_ms = float(np.mean(kernel_ms))
     per_rank = [[float(total_bytes), float(n), k_ms, float(lengths.max()) if n else 0.0]]
@@ -822,6 +837,7 @@ def main():
         flag = torch.tensor([1.0 if run_e2e else 0.0], dtype=torch.float64)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         run_e2e = bool(flag.item() > 0)
+    log(f"end-to-end leg: {run_e2e}")
     if run_e2e:
         holder = {"buf": buf}
         del buf
@@ -831,6 +847,12 @@ def main():
         del buf
     torch.cuda.empty_cache()
 
+    locked = bool(e2e and e2e["page_locked"])
+    if dist is not None and run_e2e:   # page-locked on every rank, or said so
+        flag = torch.tensor([1.0 if locked else 0.0], dtype=torch.float64)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        locked = bool(flag.item() > 0)
+    log("end-to-end leg done")
     if rank != 0:
         return finish()
 
@@ -871,11 +893,6 @@ def main():
     }
     if e2e is not None:
         bw = h2d_bandwidth(torch, device)
-        locked = e2e["page_locked"]
-        if dist is not None:
-            flag = torch.tensor([1.0 if locked else 0.0], dtype=torch.float64)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            locked = bool(flag.item() > 0)
         out["end_to_end"] = {
             "value": job_bytes / e2e["seconds"] / GB, "unit": "GB/s",
             "ms": e2e["seconds"] * 1e3,
