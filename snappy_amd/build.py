@@ -52,6 +52,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     hipcc = _hipcc()
     common = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wextra",
               "-Wno-unused-parameter"]
+    # Measurement builds: e.g. SNAPPY_EXTRA_CXXFLAGS=-DSNAPPY_LZ4_PHASE_SWITCHES with --force.
+    common += os.environ.get("SNAPPY_EXTRA_CXXFLAGS", "").split()
     objs = []
     for src in srcs:
         obj = os.path.join(objdir, os.path.basename(src) + ".o")

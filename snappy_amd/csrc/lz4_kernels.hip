@@ -52,7 +52,7 @@ __device__ __forceinline__ void wait_for_lds() { __builtin_amdgcn_s_waitcnt(0xC0
 // kStageBlocks blocks of 256 bytes per trip.  Tokens are parsed out of a
 // 256-byte window in registers, one dword per lane, which starts at any dword
 // and is moved on with one LDS read.
-constexpr uint32_t kStageBlocks = 32;  // 8 KiB per wave
+constexpr uint32_t kStageBlocks = 24;  // 6 KiB per wave
 constexpr uint32_t kJumpBlocks = 4;    // staged after a jump (a long literal run was skipped)
 
 struct InputWindow {
@@ -484,19 +484,92 @@ __device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v)
     return v;
 }
 
+// Where the tokens of the next sequences start, for up to 64 sequences at once.
+// Followed one after the other, each start costs a dependent chain through both
+// units (v_readlane -> scalar arithmetic -> the next v_readlane's lane number),
+// some 290 clocks per token.  Here every byte position p of a window of
+// kWalkWindow input bytes is given next(p), the start of the following token if
+// a token started at p (that takes the token and the byte behind it, nothing
+// else), and the table is then composed with itself: after k rounds it holds
+// next^(2^k).  Lane j reaches next^j(0) by applying the tables of the set bits of
+// j as they come by, so sequence j's start is known after six rounds of table
+// look-ups that all lanes do side by side, with no serial step at all.
+// Positions past the window (or past `last`, the last position a sequence may
+// start at) are the sentinel, which maps to itself.
+constexpr uint32_t kWalkWindow = 1024;
+constexpr uint32_t kWalkSentinel = kWalkWindow;
+constexpr uint32_t kWalkTable = kWalkWindow + 64u;  // uint16_t entries per table; two tables per wave
+constexpr uint32_t kWalkPerLane = kWalkWindow / kWave;
+
+// Returns the number of starts found (at least 1); lane j < that number gets
+// sequence j's start, relative to `bytes`, in `rel`.
+__device__ __forceinline__ uint32_t find_token_starts(const uint8_t *bytes, uint16_t *jump, uint32_t last,
+                                                      uint32_t lane, uint32_t &rel)
+{
+    uint16_t *tab = jump, *other = jump + kWalkTable;
+    // All reads first, then the arithmetic, then the writes: each group is issued
+    // back to back and waited for once.
+    uint32_t t[kWalkPerLane];
+#pragma unroll
+    for (uint32_t q = 0; q < kWalkPerLane; ++q) {
+        uint16_t two;
+        __builtin_memcpy(&two, bytes + q * kWave + lane, 2);  // the token and the byte behind it
+        t[q] = two;
+    }
+#pragma unroll
+    for (uint32_t q = 0; q < kWalkPerLane; ++q) {
+        const uint32_t p = q * kWave + lane;
+        const uint32_t r = t[q];
+        const uint32_t lit = (r >> 4) & 15u;
+        uint32_t nx = p + 3u + lit + ((r & 15u) == 15u ? 1u : 0u);
+        nx += lit == 15u ? 1u + (r >> 8) : 0u;
+        // nx > p, so one comparison covers both the start and its successor
+        t[q] = nx > last ? kWalkSentinel : nx;
+    }
+#pragma unroll
+    for (uint32_t q = 0; q < kWalkPerLane; ++q)
+        tab[q * kWave + lane] = static_cast<uint16_t>(t[q]);
+    tab[kWalkSentinel + lane] = static_cast<uint16_t>(kWalkSentinel);
+    other[kWalkSentinel + lane] = static_cast<uint16_t>(kWalkSentinel);
+    uint32_t cur = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 6u; ++k) {
+        if ((lane >> k) & 1u)
+            cur = tab[cur];
+        if (k == 5u)
+            break;
+#pragma unroll
+        for (uint32_t q = 0; q < kWalkPerLane; ++q)
+            t[q] = tab[q * kWave + lane];
+#pragma unroll
+        for (uint32_t q = 0; q < kWalkPerLane; ++q)
+            t[q] = tab[t[q]];
+#pragma unroll
+        for (uint32_t q = 0; q < kWalkPerLane; ++q)
+            other[q * kWave + lane] = static_cast<uint16_t>(t[q]);
+        uint16_t *swap = tab;
+        tab = other;
+        other = swap;
+    }
+    rel = cur;
+    const uint64_t beyond = __builtin_amdgcn_ballot_w64(cur >= kWalkSentinel);
+    return beyond ? static_cast<uint32_t>(__builtin_ctzll(beyond)) : kWave;
+}
+
 // Returns the number of sequences taken.  `walk` is how many tokens the next call
 // should look at: a stream of sequences that are not for this code should not pay
 // for 64 tokens walked in vain each time.
-__device__ __forceinline__ uint32_t take_batch(InputWindow &win, uint8_t *dst, uint8_t *ring,
+__device__ __forceinline__ uint32_t take_batch(InputWindow &win, uint8_t *dst, uint8_t *ring, uint16_t *jump,
                                                uint32_t &ip_io, uint32_t &op_io, uint32_t valid_from,
-                                               uint32_t iend, uint32_t oend, uint32_t &walk,
+                                               uint32_t iend, uint32_t oend, uint32_t &walk, bool &short_tokens,
                                                uint32_t lane, uint32_t tuning, PhaseClock &clk)
 {
     PHASE_MARK(clk, 5);
     uint32_t ip = ip_io;  // uniform
     const uint32_t start = op_io;
     const bool likely = walk >= 16u;  // recent batches were worth their while
-    if (ip < win.stage_block * 256u || ip + (likely ? 8u : 1u) * kBatchInput > win.stage_end()) {
+    const uint32_t ahead = likely ? (short_tokens ? kWalkWindow : 3u * kBatchInput) : 0u;
+    if (ip < win.stage_block * 256u || ip + kBatchInput + ahead > win.stage_end()) {
         // Not enough staged for a batch.  Staging more pays when batches have been
         // taken lately; otherwise the one-at-a-time code stages what it needs.
         if (!likely || ip + kBatchInput > iend)
@@ -515,17 +588,32 @@ __device__ __forceinline__ uint32_t take_batch(InputWindow &win, uint8_t *dst, u
     // from there on meaningless; the lanes find that out below and the batch ends
     // in front of such a sequence.
     const uint32_t ip_limit = stage_end - kBatchInput;  // at least kJumpBlocks blocks are staged
-    while (ip <= ip_limit) {
-        const uint32_t r = uni(win.peek32(ip, lane));
-        const uint32_t lit = (r >> 4) & 15u;
-        uint32_t len = 3u + lit + ((r & 15u) == 15u ? 1u : 0u);
-        if (lit == 15u)
-            len += 1u + ((r >> 8) & 255u);
-        my_ip = (lane == n) ? ip : my_ip;
-        ++n;
-        ip += len;
-        if (__builtin_expect(n >= walk, 0))
-            break;
+    bool doubled = false;
+    if (likely && short_tokens && ip <= ip_limit && !(tuning & 16u)) {
+        // Many sequences are expected, and the last batch's took 16 input bytes or fewer
+        // each, so that a window holds some 64 of them: all their starts at once.  (The
+        // table work grows with the window, not with the tokens in it: on longer
+        // sequences following them one by one is cheaper.)
+        uint32_t rel = 0;
+        const uint32_t room = ip_limit - ip;
+        n = find_token_starts(reinterpret_cast<const uint8_t *>(win.stage) + (ip - win.stage_block * 256u), jump,
+                              room < kWalkWindow - 1u ? room : kWalkWindow - 1u, lane, rel);
+        n = n < walk ? n : walk;
+        my_ip = lane < n ? ip + rel : 0u;
+        doubled = true;
+    } else {
+        while (ip <= ip_limit) {
+            const uint32_t r = uni(win.peek32(ip, lane));
+            const uint32_t lit = (r >> 4) & 15u;
+            uint32_t len = 3u + lit + ((r & 15u) == 15u ? 1u : 0u);
+            if (lit == 15u)
+                len += 1u + ((r >> 8) & 255u);
+            my_ip = (lane == n) ? ip : my_ip;
+            ++n;
+            ip += len;
+            if (__builtin_expect(n >= walk, 0))
+                break;
+        }
     }
     PHASE_MARK(clk, 0);
     if (n == 0) {
@@ -568,10 +656,19 @@ __device__ __forceinline__ uint32_t take_batch(InputWindow &win, uint8_t *dst, u
     walk = take >= walk ? (2u * walk < kWave ? 2u * walk : kWave) : (take + 4u < kWave ? take + 4u : kWave);
     if (take == 0)
         return 0;
+    // All walked sequences taken: the next token follows the last of them (its `after`
+    // is exact, the sequence having been found plain).
+    if (doubled)
+        ip = __builtin_amdgcn_readlane(after, n - 1u);
+    const uint32_t ip_before = ip_io;
     ip_io = take < n ? __builtin_amdgcn_readlane(my_ip, take) : ip;
     op_io = __builtin_amdgcn_readlane(out_end, take - 1u);
+    short_tokens = take >= 16u && ip_io - ip_before <= 16u * take;
 
     PHASE_MARK(clk, 1);
+#ifdef SNAPPY_LZ4_PHASE_SWITCHES
+    clk.acc[7] += (uint64_t(1) << 32) | take;  // batches taken, sequences in them
+#endif
     const bool mine = lane < take;
     const uint32_t my_lit = mine ? lit : 0u;
     const uint32_t my_ml = mine ? ml : 0u;
@@ -667,7 +764,7 @@ __device__ __forceinline__ uint32_t take_batch(InputWindow &win, uint8_t *dst, u
 // Decodes one compressed chunk; returns true when the block is well-formed.
 __device__ bool decode_block(const uint8_t *__restrict__ in_base, uint64_t in_alloc,
                              const Lz4Chunk &ck, uint8_t *out_base, uint8_t *ring, uint32_t *stage,
-                             uint32_t lane, uint32_t tuning, PhaseClock &clk)
+                             uint16_t *jump, uint32_t lane, uint32_t tuning, PhaseClock &clk)
 {
     const uint8_t *src = in_base + ck.in_off;
     uint8_t *dst = out_base + ck.out_off;
@@ -686,6 +783,7 @@ __device__ bool decode_block(const uint8_t *__restrict__ in_base, uint64_t in_al
     uint32_t op = 0;         // uniform
     uint32_t valid_from = 0; // uniform: the ring holds output positions [valid_from, op)
     uint32_t walk = kWave;   // uniform: tokens the next batch looks at
+    bool short_tokens = false;  // uniform: the last batch's sequences took 16 input bytes or fewer each
     uint32_t misses = 0, skip = 0;  // uniform: back-off of the batch attempts on streams of long sequences
     const uint8_t *src_al = src - in_shift;
 
@@ -693,7 +791,8 @@ __device__ bool decode_block(const uint8_t *__restrict__ in_base, uint64_t in_al
         if (skip != 0u) {
             --skip;
         } else if (!(tuning & 1u)) {
-            const uint32_t taken = take_batch(win, dst, ring, ip, op, valid_from, iend, oend, walk, lane, tuning, clk);
+            const uint32_t taken = take_batch(win, dst, ring, jump, ip, op, valid_from, iend, oend, walk, short_tokens, lane,
+                                              tuning, clk);
             if (taken >= 16u)
                 continue;  // more of the same is likely
             // Attempts that take nothing back off: 1, 3, 7, 15 sequences go by before the next one.
@@ -810,6 +909,7 @@ lz4_decode_kernel(const uint8_t *__restrict__ in_base, uint64_t in_alloc, uint8_
     __shared__ __attribute__((aligned(16))) uint8_t ring[kHist];
     const uint32_t lane = threadIdx.x & (kWave - 1);
     __shared__ uint32_t stage[kStageBlocks * 64u];
+    __shared__ uint16_t jump[2u * kWalkTable];
     for (;;) {
         const uint32_t i = wave_claim(queue, 1u, lane);
         if (i >= n_chunks)
@@ -819,7 +919,7 @@ lz4_decode_kernel(const uint8_t *__restrict__ in_base, uint64_t in_alloc, uint8_
         if (ck.compressed) {
             PhaseClock clk;
             clk.start();
-            ok = decode_block(in_base, in_alloc, ck, out_base, ring, stage, lane, tuning, clk);
+            ok = decode_block(in_base, in_alloc, ck, out_base, ring, stage, jump, lane, tuning, clk);
             PHASE_MARK(clk, 5);
             clk.flush(lane);
         } else {
@@ -843,7 +943,7 @@ hipError_t launch_lz4_decode(const uint8_t *d_in, uint64_t in_alloc, uint8_t *d_
     // waves than the chip holds would crowd some CUs and leave others idle (1024
     // chunks: 11 % slower).  Each workgroup therefore asks for so much LDS that
     // only its share of a CU's 160 KiB fits: the waves spread evenly.
-    constexpr uint32_t kWavesPerCu = 8, kLdsPerCu = 156u << 10, kLdsUsed = kHist + kStageBlocks * 256u;
+    constexpr uint32_t kWavesPerCu = 8, kLdsPerCu = 156u << 10, kLdsUsed = kHist + kStageBlocks * 256u + 4u * kWalkTable;
     const uint32_t blocks = static_cast<uint32_t>(
         std::min<uint64_t>(n_chunks, static_cast<uint64_t>(n_cu) * kWavesPerCu));
     const uint32_t per_cu = (blocks + static_cast<uint32_t>(n_cu) - 1u) / static_cast<uint32_t>(n_cu);
@@ -873,7 +973,8 @@ hipError_t launch_lz4_decode(const uint8_t *d_in, uint64_t in_alloc, uint8_t *d_
     unsigned long long c[8];
     (void)hipMemcpyFromSymbol(c, HIP_SYMBOL(g_phase_cycles), sizeof c);
     fprintf(stderr, "lz4 phases (s_memtime ticks summed over %u chunks): walk %llu classify %llu literals %llu "
-                    "old sources %llu rounds %llu one-at-a-time %llu staging %llu\n", n_chunks, c[0], c[1], c[2], c[3], c[4], c[5], c[6]);
+                    "old sources %llu rounds %llu one-at-a-time %llu staging %llu; %llu batches of %.1f sequences\n", n_chunks, c[0], c[1], c[2], c[3], c[4], c[5], c[6],
+            c[7] >> 32, static_cast<double>(c[7] & 0xFFFFFFFFull) / static_cast<double>((c[7] >> 32) ? (c[7] >> 32) : 1));
 #endif
     return hipGetLastError();
 }
