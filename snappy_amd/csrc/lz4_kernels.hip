@@ -787,7 +787,12 @@ __device__ bool decode_block(const uint8_t *__restrict__ in_base, uint64_t in_al
     uint32_t misses = 0, skip = 0;  // uniform: back-off of the batch attempts on streams of long sequences
     const uint8_t *src_al = src - in_shift;
 
+    // A chunk may be asked for in part (its first bytes hold an archive's header): the
+    // decode then ends, well-formed so far, once that much output exists.
+    const uint32_t stop_at = ck.prefix_len ? ck.prefix_len : 0xFFFFFFFFu;
     for (;;) {
+        if (op >= stop_at)
+            return true;
         if (skip != 0u) {
             --skip;
         } else if (!(tuning & 1u)) {
@@ -910,6 +915,10 @@ lz4_decode_kernel(const uint8_t *__restrict__ in_base, uint64_t in_alloc, uint8_
     const uint32_t lane = threadIdx.x & (kWave - 1);
     __shared__ uint32_t stage[kStageBlocks * 64u];
     __shared__ uint16_t jump[2u * kWalkTable];
+    // In an MCDF import the decoder runs next to a SHA-1 kernel whose waves issue an
+    // instruction in nearly every slot of their SIMD.  A decoder wave spends most of its
+    // time waiting for memory and LDS; when it is ready it should not queue behind that.
+    __builtin_amdgcn_s_setprio(3);
     for (;;) {
         const uint32_t i = wave_claim(queue, 1u, lane);
         if (i >= n_chunks)

@@ -15,7 +15,7 @@ struct Lz4Chunk {
     uint32_t comp_len;    // payload bytes in the stream
     uint32_t orig_len;    // decoded bytes
     uint32_t compressed;  // 0 = stored
-    uint32_t reserved;
+    uint32_t prefix_len;  // != 0: only the first prefix_len decoded bytes are wanted (at least; compressed chunks)
 };
 
 // Decodes n_chunks chunks.  d_in holds the stream and at least in_alloc

@@ -99,7 +99,7 @@ void parse_lz4net_stream(const uint8_t *in, uint64_t in_len, Lz4netLayout &layou
     }
 }
 
-int decode_streams_on_device(SlotLease &lease, std::vector<StreamJob> &jobs)
+int prepare_streams(SlotLease &lease, std::vector<StreamJob> &jobs, StreamPlan &plan, size_t extra_chunks)
 {
     Slot &s = *lease.slot;
     // A chunk header is a dozen bytes and may declare 2 GiB of output.  An LZ4 block
@@ -168,29 +168,32 @@ int decode_streams_on_device(SlotLease &lease, std::vector<StreamJob> &jobs)
         j.d_payload = arena + j.out_off;
         j.status = j.layout.stop_status;
     }
-    if (n_chunks == 0)
-        return SNAPPY_OK;
+    plan.in_alloc = in_alloc;
+    plan.n_chunks = n_chunks;
+    plan.first_chunk.assign(jobs.size() + 1, 0);
     if (n_chunks > 0xFFFFFFF0ull)
         return SNAPPY_E_INVALID_ARG;
 
-    const size_t table_bytes = n_chunks * sizeof(Lz4Chunk);
-    const size_t status_bytes = n_chunks * sizeof(uint32_t);
-    if ((st = s.d_tasks.ensure(table_bytes)) != SNAPPY_OK) return st;
-    if ((st = s.d_out.ensure(status_bytes)) != SNAPPY_OK) return st;
-    if ((st = s.d_misc.ensure(256)) != SNAPPY_OK) return st;
-    if ((st = s.h_stage.ensure(std::max(table_bytes, status_bytes))) != SNAPPY_OK) return st;
+    const size_t rows = static_cast<size_t>(n_chunks) + extra_chunks;
+    const size_t table_bytes = rows * sizeof(Lz4Chunk);
+    const size_t status_bytes = rows * sizeof(uint32_t);
+    plan.queue_words = 16u * (jobs.size() + 2u);  // a launch's queue counter every 64 bytes
+    if ((st = s.d_chunks.ensure(std::max<size_t>(table_bytes, 256))) != SNAPPY_OK) return st;
+    if ((st = s.d_status.ensure(std::max<size_t>(status_bytes, 256))) != SNAPPY_OK) return st;
+    if ((st = s.d_queues.ensure(plan.queue_words * sizeof(uint32_t))) != SNAPPY_OK) return st;
+    if ((st = s.h_stage.ensure(std::max<size_t>(std::max(table_bytes, status_bytes), 256) +
+                               (jobs.size() + 2u) * sizeof(uint32_t))) != SNAPPY_OK) return st;
 
     hipStream_t stream = s.stream;
     Lz4Chunk *table = static_cast<Lz4Chunk *>(s.h_stage.ptr);
     uint64_t k = 0;
-    std::vector<Piece> pieces;
-    for (StreamJob &j : jobs) {
+    for (size_t a = 0; a < jobs.size(); ++a) {
+        StreamJob &j = jobs[a];
+        plan.first_chunk[a] = k;
         if (j.dropped)
             continue;
         const uint64_t region = (j.in_len + 256 + 255) & ~uint64_t(255);
         SNAPPY_HIP_TRY(hipMemsetAsync(arena + j.in_off + j.in_len, 0, region - j.in_len, stream));
-        if (j.in_len)
-            pieces.push_back({j.in, j.in_off, j.in_len});
         for (const Lz4Chunk &c : j.layout.chunks) {
             table[k] = c;
             table[k].in_off += j.in_off;
@@ -198,9 +201,46 @@ int decode_streams_on_device(SlotLease &lease, std::vector<StreamJob> &jobs)
             ++k;
         }
     }
-    SNAPPY_HIP_TRY(hipMemcpyAsync(s.d_tasks.ptr, s.h_stage.ptr, table_bytes, hipMemcpyHostToDevice,
-                                  stream));
-    SNAPPY_HIP_TRY(hipMemsetAsync(s.d_misc.ptr, 0, 256, stream));
+    plan.first_chunk[jobs.size()] = k;
+    if (n_chunks)
+        SNAPPY_HIP_TRY(hipMemcpyAsync(s.d_chunks.ptr, s.h_stage.ptr, static_cast<size_t>(n_chunks) * sizeof(Lz4Chunk),
+                                      hipMemcpyHostToDevice, stream));
+    SNAPPY_HIP_TRY(hipMemsetAsync(s.d_queues.ptr, 0, plan.queue_words * sizeof(uint32_t), stream));
+    SNAPPY_HIP_TRY(hipStreamSynchronize(stream));  // the staging buffer may be reused from here on
+    return SNAPPY_OK;
+}
+
+int collect_decode_status(SlotLease &lease, std::vector<StreamJob> &jobs, const StreamPlan &plan)
+{
+    Slot &s = *lease.slot;
+    if (plan.n_chunks == 0)
+        return SNAPPY_OK;
+    SNAPPY_HIP_TRY(hipMemcpy(s.h_stage.ptr, s.d_status.ptr, static_cast<size_t>(plan.n_chunks) * sizeof(uint32_t),
+                             hipMemcpyDeviceToHost));
+    // A malformed block comes before whatever ended the header walk after it.
+    const uint32_t *status = static_cast<const uint32_t *>(s.h_stage.ptr);
+    uint64_t k = 0;
+    for (StreamJob &j : jobs) {
+        for (size_t c = 0; c < j.layout.chunks.size(); ++c, ++k)
+            if (status[k] != 0)
+                j.status = SNAPPY_E_LZ4_CORRUPT;
+    }
+    return SNAPPY_OK;
+}
+
+int decode_streams_on_device(SlotLease &lease, std::vector<StreamJob> &jobs)
+{
+    Slot &s = *lease.slot;
+    StreamPlan plan;
+    int st = prepare_streams(lease, jobs, plan, 0);
+    if (st != SNAPPY_OK || plan.n_chunks == 0)
+        return st;
+    uint8_t *arena = static_cast<uint8_t *>(s.d_data.ptr);
+    hipStream_t stream = s.stream;
+    std::vector<Piece> pieces;
+    for (StreamJob &j : jobs)
+        if (!j.dropped && j.in_len)
+            pieces.push_back({j.in, j.in_off, j.in_len});
     // The compressed streams travel on the copy stream (through the page-locked ring
     // when they lie in ordinary memory); the call returns when they have landed.
     SNAPPY_HIP_TRY(transfer_to_device(s, lease.dev->hip_device, pieces, kTransferSliceBytes, arena,
@@ -209,30 +249,20 @@ int decode_streams_on_device(SlotLease &lease, std::vector<StreamJob> &jobs)
     const bool prof = profiling_enabled();
     if (prof)
         SNAPPY_HIP_TRY(hipEventRecord(s.ev_prof[1][0], stream));
-    SNAPPY_HIP_TRY(launch_lz4_decode(arena, in_alloc, arena,
-                                     static_cast<const Lz4Chunk *>(s.d_tasks.ptr),
-                                     static_cast<uint32_t>(n_chunks),
-                                     static_cast<uint32_t *>(s.d_misc.ptr),
-                                     static_cast<uint32_t *>(s.d_out.ptr), lease.dev->n_cu, stream));
+    SNAPPY_HIP_TRY(launch_lz4_decode(arena, plan.in_alloc, arena,
+                                     static_cast<const Lz4Chunk *>(s.d_chunks.ptr),
+                                     static_cast<uint32_t>(plan.n_chunks),
+                                     static_cast<uint32_t *>(s.d_queues.ptr),
+                                     static_cast<uint32_t *>(s.d_status.ptr), lease.dev->n_cu, stream));
     if (prof)
         SNAPPY_HIP_TRY(hipEventRecord(s.ev_prof[1][1], stream));
-    // The status words must be on the host before the staging buffer is reused.
     SNAPPY_HIP_TRY(hipStreamSynchronize(stream));
-    SNAPPY_HIP_TRY(hipMemcpy(s.h_stage.ptr, s.d_out.ptr, status_bytes, hipMemcpyDeviceToHost));
     if (prof) {
         float ms = -1.f;
         if (hipEventElapsedTime(&ms, s.ev_prof[1][0], s.ev_prof[1][1]) == hipSuccess)
             profile_store(1, ms);
     }
-    // A malformed block comes before whatever ended the header walk after it.
-    const uint32_t *status = static_cast<const uint32_t *>(s.h_stage.ptr);
-    k = 0;
-    for (StreamJob &j : jobs) {
-        for (size_t c = 0; c < j.layout.chunks.size(); ++c, ++k)
-            if (status[k] != 0)
-                j.status = SNAPPY_E_LZ4_CORRUPT;
-    }
-    return SNAPPY_OK;
+    return collect_decode_status(lease, jobs, plan);
 }
 
 int decode_lz4net_on_device(SlotLease &lease, const uint8_t *in, uint64_t in_len,

@@ -42,6 +42,25 @@ struct StreamJob {
     bool dropped = false;  // given up for lack of device memory (status SNAPPY_E_NOMEM)
 };
 
+// Where a batch of streams lies in the slot's device arena and in its chunk
+// table, once prepare_streams has laid it out.
+struct StreamPlan {
+    uint64_t in_alloc = 0;               // bytes of the arena's input part (streams + slack)
+    uint64_t n_chunks = 0;               // rows of the chunk table in slot.d_tasks
+    std::vector<uint64_t> first_chunk;   // job a owns rows first_chunk[a] .. first_chunk[a + 1]
+    size_t queue_words = 0;              // zeroed 32-bit words in slot.d_misc: word 16 * k is launch k's queue
+};
+
+// Lays the streams and their payloads out in the slot's device arena, sizes every
+// buffer a decode needs (with room for extra_chunks more table rows and status
+// words behind the batch's own), uploads the chunk table and clears the queue
+// words.  Moves no stream.  Per-stream outcomes so far are in jobs[i].status.
+int prepare_streams(SlotLease &lease, std::vector<StreamJob> &jobs, StreamPlan &plan, size_t extra_chunks);
+
+// After the decode launches have finished: marks the streams with a malformed
+// block SNAPPY_E_LZ4_CORRUPT.
+int collect_decode_status(SlotLease &lease, std::vector<StreamJob> &jobs, const StreamPlan &plan);
+
 // Uploads all streams and decodes all their chunks in one launch, so that a
 // batch of archives fills the GPU (a 1 MiB chunk is one wavefront's work).
 // Returns an infrastructure status; per-stream results are in jobs[i].status.

@@ -6,6 +6,7 @@
 // one decode launch and one hash launch: an archive is only 64-512 chunks, too
 // few to occupy the GPU on its own.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 
@@ -23,6 +24,409 @@ struct ArchiveState {
     McdfHeaderInfo info;
     std::vector<McdfSlice> slices;
 };
+
+// Parses the header of archive a out of its decoded payload on the device and
+// slices its files; appends the bodies to hash to (offsets, lengths, owner).
+int header_and_slices(uint8_t *arena, const StreamJob &job, size_t a, uint64_t decoded_avail, ArchiveState &as,
+                      std::vector<uint8_t> &digests_out, std::vector<uint64_t> &offsets,
+                      std::vector<uint64_t> &lengths, std::vector<std::pair<size_t, size_t>> &owner,
+                      bool *header_beyond_avail)
+{
+    const uint64_t size = job.layout.decoded_size;
+    // Header: 9 bytes tell how much JSON follows.
+    uint8_t head[9] = {0};
+    const uint64_t head_len = size < 9 ? size : 9;
+    if (head_len > decoded_avail) {
+        *header_beyond_avail = true;
+        return SNAPPY_OK;
+    }
+    if (head_len)
+        SNAPPY_HIP_TRY(hipMemcpy(head, job.d_payload, head_len, hipMemcpyDeviceToHost));
+    uint64_t need = 0;
+    as.status = mcdf_header_extent(head, head_len, size, &need);
+    if (as.status != SNAPPY_OK)
+        return SNAPPY_OK;
+    if (need > decoded_avail) {
+        *header_beyond_avail = true;
+        return SNAPPY_OK;
+    }
+    std::vector<uint8_t> header(static_cast<size_t>(need));
+    SNAPPY_HIP_TRY(hipMemcpy(header.data(), job.d_payload, need, hipMemcpyDeviceToHost));
+    as.status = parse_mcdf_header(header.data(), need, as.info);
+    if (as.status != SNAPPY_OK)
+        return SNAPPY_OK;
+    as.status = mcdf_slice_files(as.info.files, as.info.body_offset, size, as.slices);
+    if (as.status != SNAPPY_OK)
+        return SNAPPY_OK;
+    digests_out.assign(as.slices.size() * 20, 0);
+    for (size_t f = 0; f < as.slices.size(); ++f) {
+        if (as.slices[f].status != SNAPPY_FILE_HASHED)
+            continue;
+        offsets.push_back(static_cast<uint64_t>(job.d_payload - arena) + as.slices[f].offset);
+        lengths.push_back(as.slices[f].length);
+        owner.emplace_back(a, f);
+    }
+    return SNAPPY_OK;
+}
+
+// The end of the overlapped import: which streams had a malformed block, and the
+// digests to their archives' places.
+int finish_overlapped(Slot &s, std::vector<StreamJob> &jobs, std::vector<ArchiveState> &states,
+                      std::vector<std::vector<uint8_t>> &digests_out, const std::vector<size_t> &order,
+                      const std::vector<uint64_t> &first_row, size_t n_rows,
+                      const std::vector<std::pair<size_t, size_t>> &owner, const std::vector<uint8_t> &packed)
+{
+    const size_t n = jobs.size();
+    const uint32_t *d_status = static_cast<const uint32_t *>(s.d_status.ptr);
+    // A malformed block comes before whatever ended the header walk after it.
+    if (n_rows) {
+        std::vector<uint32_t> chunk_status(n_rows);
+        SNAPPY_HIP_TRY(hipMemcpy(chunk_status.data(), d_status, n_rows * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        for (size_t k = 0; k < order.size(); ++k)
+            for (uint64_t r = first_row[k]; r < first_row[k + 1]; ++r)
+                if (chunk_status[r] != 0)
+                    jobs[order[k]].status = SNAPPY_E_LZ4_CORRUPT;
+    }
+    for (size_t a = 0; a < n; ++a)
+        if (jobs[a].status != SNAPPY_OK && states[a].status == SNAPPY_OK) {
+            states[a].status = jobs[a].status;  // a later block of the stream was malformed
+            digests_out[a].clear();
+        }
+    for (size_t k = 0; k < owner.size(); ++k)
+        if (states[owner[k].first].status == SNAPPY_OK)
+            std::memcpy(digests_out[owner[k].first].data() + 20 * owner[k].second, packed.data() + 20 * k, 20);
+    return SNAPPY_OK;
+}
+
+// Decoded bytes of an archive's first chunk that are asked for ahead of the rest:
+// room for the header of some 1500 files.
+constexpr uint32_t kHeaderPrefix = 128u << 10;
+
+// The import with its three stages overlapped.  Hashing can only be planned once
+// every archive's header is known, and the headers are inside the compressed
+// streams; but a header sits in an archive's first chunk.  So: the first chunk of
+// every archive is sent and decoded ahead (a few MB), the headers are parsed, and
+// the SHA-1 kernel is launched at once, every file waiting for its archive's
+// number on the arrival counter.  The archives then follow whole, the one with
+// the largest file first: copy, decode, raise the counter.  The largest file's
+// chain, which decides the finishing time, starts after one archive's transfer
+// instead of after all of them.
+// Returns SNAPPY_OK with *handled = false when the batch is not for this path.
+int import_batch_overlapped(SlotLease &lease, std::vector<StreamJob> &jobs, std::vector<ArchiveState> &states,
+                            std::vector<std::vector<uint8_t>> &digests_out, bool *handled)
+{
+    *handled = false;
+    Slot &s = *lease.slot;
+    const size_t n = jobs.size();
+    uint64_t stream_bytes = 0;
+    for (const StreamJob &j : jobs)
+        stream_bytes += j.in_len;
+    // SNAPPY_OVERLAP_MIN_BYTES: tests and tuning (the same switch as the SHA-1 entry points').
+    const char *min_text = std::getenv("SNAPPY_OVERLAP_MIN_BYTES");
+    const uint64_t min_bytes = min_text ? std::strtoull(min_text, nullptr, 10) : (64ull << 20);
+    if (s.d_flags == nullptr || stream_bytes < min_bytes || n >= 0x7FFFFFFFull)
+        return SNAPPY_OK;
+    WaitingKernelTurn turn(lease.dev->hip_device);
+    if (!turn.mine())
+        return SNAPPY_OK;
+
+    StreamPlan plan;
+    int st = prepare_streams(lease, jobs, plan, n);
+    if (st != SNAPPY_OK)
+        return st;
+    *handled = true;  // from here on the batch is laid out for this path
+    uint8_t *arena = static_cast<uint8_t *>(s.d_data.ptr);
+    const int hip_device = lease.dev->hip_device;
+    Lz4Chunk *d_table = static_cast<Lz4Chunk *>(s.d_chunks.ptr);
+    uint32_t *d_queue = static_cast<uint32_t *>(s.d_queues.ptr);
+    uint32_t *d_status = static_cast<uint32_t *>(s.d_status.ptr);
+
+    // 1. The first chunk of every archive: send, decode, read the headers.
+    float first_chunks_ms = 0.f;  // how long one chunk of this content takes to decode
+    std::vector<Lz4Chunk> firsts;
+    std::vector<size_t> first_of(n, SIZE_MAX);
+    std::vector<Piece> pieces;
+    for (size_t a = 0; a < n; ++a) {
+        states[a].status = jobs[a].status;
+        if (jobs[a].dropped || jobs[a].layout.chunks.empty())
+            continue;
+        Lz4Chunk c = jobs[a].layout.chunks[0];
+        pieces.push_back({jobs[a].in + c.in_off, jobs[a].in_off + c.in_off, c.comp_len});
+        c.in_off += jobs[a].in_off;
+        c.out_off += jobs[a].out_off;
+        c.prefix_len = kHeaderPrefix < c.orig_len ? kHeaderPrefix : 0u;
+        first_of[a] = firsts.size();
+        firsts.push_back(c);
+    }
+    if (!firsts.empty()) {
+        SNAPPY_HIP_TRY(transfer_to_device(s, hip_device, pieces, kTransferSliceBytes, arena, nullptr, nullptr));
+        SNAPPY_HIP_TRY(hipMemcpyAsync(d_table + plan.n_chunks, firsts.data(), firsts.size() * sizeof(Lz4Chunk),
+                                      hipMemcpyHostToDevice, s.stream));
+        SNAPPY_HIP_TRY(hipEventRecord(s.ev_prof[1][0], s.stream));
+        SNAPPY_HIP_TRY(launch_lz4_decode(arena, plan.in_alloc, arena, d_table + plan.n_chunks,
+                                         static_cast<uint32_t>(firsts.size()), d_queue + 16u * (n + 1u),
+                                         d_status + plan.n_chunks, lease.dev->n_cu, s.stream));
+        SNAPPY_HIP_TRY(hipEventRecord(s.ev_prof[1][1], s.stream));
+        SNAPPY_HIP_TRY(hipStreamSynchronize(s.stream));
+        if (hipEventElapsedTime(&first_chunks_ms, s.ev_prof[1][0], s.ev_prof[1][1]) != hipSuccess) {
+            (void)hipGetLastError();
+            first_chunks_ms = 0.f;
+        }
+    }
+    std::vector<uint32_t> first_status(firsts.size(), 0);
+    if (!firsts.empty())
+        SNAPPY_HIP_TRY(hipMemcpy(first_status.data(), d_status + plan.n_chunks, firsts.size() * sizeof(uint32_t),
+                                 hipMemcpyDeviceToHost));
+    std::vector<uint64_t> offsets, lengths;
+    std::vector<std::pair<size_t, size_t>> owner;  // (archive, file)
+    bool header_beyond = false;
+    for (size_t a = 0; a < n; ++a) {
+        ArchiveState &as = states[a];
+        // A stream error ends the import before anything looks at the header; a first
+        // chunk that does not decode is the stream's first error.
+        if (first_of[a] != SIZE_MAX && first_status[first_of[a]] != 0)
+            jobs[a].status = as.status = SNAPPY_E_LZ4_CORRUPT;
+        if (as.status != SNAPPY_OK)
+            continue;
+        const Lz4Chunk *fc = first_of[a] == SIZE_MAX ? nullptr : &firsts[first_of[a]];
+        const uint64_t avail = !fc ? 0 : (fc->prefix_len ? fc->prefix_len : fc->orig_len);
+        st = header_and_slices(arena, jobs[a], a, avail, as, digests_out[a], offsets, lengths, owner, &header_beyond);
+        if (st != SNAPPY_OK)
+            return st;
+    }
+    if (header_beyond || owner.size() >= 0xFFFFFFF0ull) {
+        // A header that runs past its archive's first chunk (many thousands of files):
+        // the plain order of things handles it.
+        *handled = false;
+        return SNAPPY_OK;
+    }
+
+    // 2. The archives in the order they will arrive: largest file first.
+    std::vector<uint64_t> largest(n, 0);
+    for (size_t k = 0; k < owner.size(); ++k)
+        largest[owner[k].first] = std::max(largest[owner[k].first], lengths[k]);
+    std::vector<size_t> order;
+    for (size_t a = 0; a < n; ++a)
+        if (!jobs[a].dropped && jobs[a].in_len)
+            order.push_back(a);
+    std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) { return largest[x] > largest[y]; });
+    std::vector<uint32_t> epoch_of(n, 0);
+    uint32_t *numbers = reinterpret_cast<uint32_t *>(static_cast<uint8_t *>(s.h_stage.ptr) + s.h_stage.cap) -
+                        (n + 2u);  // page-locked words the counter is raised from
+    for (size_t k = 0; k < order.size(); ++k) {
+        epoch_of[order[k]] = static_cast<uint32_t>(k + 1);
+        numbers[k] = static_cast<uint32_t>(k + 1);
+    }
+    // The chunk table once more, in arrival order, so that any run of consecutive
+    // arrivals can be decoded by one launch.
+    std::vector<Lz4Chunk> ordered;
+    std::vector<uint64_t> first_row(order.size() + 1, 0);
+    for (size_t k = 0; k < order.size(); ++k) {
+        const StreamJob &j = jobs[order[k]];
+        first_row[k] = ordered.size();
+        for (Lz4Chunk c : j.layout.chunks) {
+            c.in_off += j.in_off;
+            c.out_off += j.out_off;
+            ordered.push_back(c);
+        }
+    }
+    first_row[order.size()] = ordered.size();
+    if (!ordered.empty())
+        SNAPPY_HIP_TRY(hipMemcpy(d_table, ordered.data(), ordered.size() * sizeof(Lz4Chunk), hipMemcpyHostToDevice));
+
+    // A chunk is decoded by one wave, and on streams of short sequences its chain of
+    // sequences takes milliseconds (long copies: 0.3 ms).  Next to a resident SHA-1
+    // kernel only half as many decoder waves fit on a CU, so decoding such archives
+    // behind their transfers one by one would hold the later ones back by more than
+    // the overlap gains.  When one chunk takes longer than an archive's transfer, the
+    // order stays the plain one: send everything, decode everything in one launch with
+    // the GPU to itself, then hash (the headers read above are not read again).
+    uint64_t mean_stream = 0;
+    for (size_t a : order)
+        mean_stream += jobs[a].in_len / order.size();
+    // (The first chunks were decoded up to kHeaderPrefix bytes: a whole chunk takes in proportion.)
+    uint64_t mean_chunk = 0;
+    for (const Lz4Chunk &c : firsts)
+        mean_chunk += c.orig_len / firsts.size();
+    const float whole_chunk_ms =
+        first_chunks_ms * (mean_chunk > kHeaderPrefix ? static_cast<float>(mean_chunk) / kHeaderPrefix : 1.f);
+    if (!order.empty() && whole_chunk_ms > static_cast<float>(mean_stream) / 50e6f) {
+        std::vector<Piece> all;
+        for (size_t a = 0; a < n; ++a)  // arena order
+            if (!jobs[a].dropped && jobs[a].in_len)
+                all.push_back({jobs[a].in, jobs[a].in_off, jobs[a].in_len});
+        SNAPPY_HIP_TRY(transfer_to_device(s, hip_device, all, kTransferSliceBytes, arena, nullptr, nullptr));
+        const bool timed = profiling_enabled();
+        if (timed)
+            SNAPPY_HIP_TRY(hipEventRecord(s.ev_prof[1][0], s.stream));
+        if (!ordered.empty())
+            SNAPPY_HIP_TRY(launch_lz4_decode(arena, plan.in_alloc, arena, d_table, static_cast<uint32_t>(ordered.size()),
+                                             d_queue, d_status, lease.dev->n_cu, s.stream));
+        if (timed)
+            SNAPPY_HIP_TRY(hipEventRecord(s.ev_prof[1][1], s.stream));
+        SNAPPY_HIP_TRY(hipStreamSynchronize(s.stream));
+        if (timed) {
+            float ms = -1.f;
+            if (hipEventElapsedTime(&ms, s.ev_prof[1][0], s.ev_prof[1][1]) == hipSuccess)
+                profile_store(1, ms);
+            else
+                (void)hipGetLastError();
+        }
+        std::vector<uint8_t> hashed(owner.size() * 20);
+        if (!owner.empty() &&
+            (st = run_sha1_tables(lease, arena, offsets.data(), lengths.data(), owner.size(), hashed.data(), nullptr)) != SNAPPY_OK)
+            return st;
+        return finish_overlapped(s, jobs, states, digests_out, order, first_row, ordered.size(), owner, hashed);
+    }
+
+    // 3. The SHA-1 kernel, waiting.  Everything it or the transfers need is allocated first.
+    const size_t n_files = owner.size();
+    const size_t table_bytes = n_files * sizeof(uint64_t);
+    uint8_t *d_digests = nullptr;
+    Sha1Arrival *d_arrival = static_cast<Sha1Arrival *>(s.d_flags);
+    const bool prof = profiling_enabled();
+    std::vector<hipEvent_t> marks;
+    struct DestroyEvents {
+        std::vector<hipEvent_t> &ev;
+        ~DestroyEvents()
+        {
+            for (hipEvent_t e : ev)
+                (void)hipEventDestroy(e);
+        }
+    } destroy_events{marks};
+    for (size_t k = 0; k < 2 * order.size(); ++k) {
+        hipEvent_t e;
+        SNAPPY_HIP_TRY(hipEventCreate(&e));
+        marks.push_back(e);
+    }
+    uint64_t largest_stream = 0;
+    for (size_t a : order)
+        largest_stream = std::max<uint64_t>(largest_stream, jobs[a].in_len);
+    if ((st = reserve_transfer_ring(s, kTransferSliceBytes, (largest_stream + kTransferSliceBytes - 1) / kTransferSliceBytes)) != SNAPPY_OK)
+        return st;
+    if (n_files) {
+        // The tables, the arrival numbers and the digests share one buffer.
+        if ((st = s.d_tables.ensure(2 * table_bytes + n_files * sizeof(uint32_t) + n_files * 20 + 64)) != SNAPPY_OK)
+            return st;
+        uint64_t *d_off = static_cast<uint64_t *>(s.d_tables.ptr);
+        uint64_t *d_len = d_off + n_files;
+        uint32_t *d_epochs = reinterpret_cast<uint32_t *>(d_len + n_files);
+        d_digests = reinterpret_cast<uint8_t *>(d_epochs + n_files);
+        std::vector<uint32_t> epochs(n_files);
+        for (size_t k = 0; k < n_files; ++k)
+            epochs[k] = epoch_of[owner[k].first];
+        Sha1Arrival zero = {};
+        zero.max_idle_polls = 200000;  // ~10 s without progress before the kernel stops waiting
+        if (const char *v = std::getenv("SNAPPY_ARRIVAL_MAX_POLLS"))
+            zero.max_idle_polls = static_cast<uint32_t>(std::strtoul(v, nullptr, 10));
+        SNAPPY_HIP_TRY(hipMemcpy(d_arrival, &zero, sizeof(zero), hipMemcpyHostToDevice));
+        SNAPPY_HIP_TRY(hipMemcpyAsync(d_off, offsets.data(), table_bytes, hipMemcpyHostToDevice, s.stream));
+        SNAPPY_HIP_TRY(hipMemcpyAsync(d_len, lengths.data(), table_bytes, hipMemcpyHostToDevice, s.stream));
+        SNAPPY_HIP_TRY(hipMemcpyAsync(d_epochs, epochs.data(), n_files * sizeof(uint32_t), hipMemcpyHostToDevice,
+                                      s.stream));
+        st = enqueue_sha1_resident(lease, arena, d_off, d_len, n_files, d_digests, s.stream, d_epochs, d_arrival);
+        if (st != SNAPPY_OK)
+            return st;  // nothing was launched that waits
+    }
+
+    // 4. The archives: copy, decode, raise the counter.  From here on a kernel may be
+    // waiting: whatever goes wrong, it has to be told.
+    // An archive's decode sits between its transfer and the next one's on the copy
+    // stream.  That is the right order while a decode is short next to a transfer
+    // (long copies: 0.3 ms against 3).  On streams of short sequences one archive's
+    // 256 chunks take as long as 2048 would (a chunk's own chain of sequences decides,
+    // some 8 ms), and eight of them in a row would hold every later archive back: when
+    // a decode has taken longer than the transfer that followed it, the remaining
+    // archives are sent first and decoded by one launch.
+    hipError_t failure = hipSuccess;
+    std::vector<std::pair<size_t, size_t>> launches;  // (first, last + 1) positions in `order` per decode launch
+    bool grouped = false;
+    size_t group_from = 0;
+    auto decode_run = [&](size_t from, size_t to) -> hipError_t {
+        const uint32_t rows = static_cast<uint32_t>(first_row[to] - first_row[from]);
+        hipError_t e = hipSuccess;
+        if (rows) {
+            e = hipEventRecord(marks[2 * from], s.copy_stream);
+            if (e == hipSuccess)
+                e = launch_lz4_decode(arena, plan.in_alloc, arena, d_table + first_row[from], rows,
+                                      d_queue + 16u * from, d_status + first_row[from], lease.dev->n_cu,
+                                      s.copy_stream);
+            if (e == hipSuccess)
+                e = hipEventRecord(marks[2 * from + 1], s.copy_stream);
+            if (e == hipSuccess)
+                launches.emplace_back(from, to);
+        }
+        if (e == hipSuccess && n_files)
+            e = hipMemcpyAsync(&d_arrival->arrived, &numbers[to - 1], sizeof(uint32_t), hipMemcpyHostToDevice,
+                               s.copy_stream);
+        return e;
+    };
+    for (size_t k = 0; k < order.size() && failure == hipSuccess; ++k) {
+        const size_t a = order[k];
+        std::vector<Piece> whole{{jobs[a].in, jobs[a].in_off, jobs[a].in_len}};
+        failure = transfer_to_device(s, hip_device, whole, kTransferSliceBytes, arena, nullptr, nullptr);
+        if (failure != hipSuccess)
+            break;
+        if (!grouped && k > 0 && !launches.empty() && launches.back().second == k) {
+            // The previous archive's decode lay ahead of this transfer on the stream: it is over.
+            float decode_ms = 0.f;
+            const size_t prev = launches.back().first;
+            if (hipEventElapsedTime(&decode_ms, marks[2 * prev], marks[2 * prev + 1]) != hipSuccess)
+                (void)hipGetLastError();
+            const float transfer_ms = static_cast<float>(jobs[a].in_len) / 50e6f;  // at PCIe rate
+            if (decode_ms > 1.5f * transfer_ms && k + 1 < order.size()) {
+                grouped = true;
+                group_from = k;
+            }
+        }
+        if (!grouped)
+            failure = decode_run(k, k + 1);
+    }
+    if (grouped && failure == hipSuccess)
+        failure = decode_run(group_from, order.size());
+    if (failure == hipSuccess)
+        failure = hipStreamSynchronize(s.copy_stream);
+    if (failure != hipSuccess) {
+        set_error_detail(std::string("MCDF import, transfer or decode: ") + hipGetErrorString(failure));
+        (void)hipGetLastError();
+        const uint32_t one = 1;
+        (void)hipMemcpy(&d_arrival->abort, &one, sizeof(one), hipMemcpyHostToDevice);
+        (void)hipStreamSynchronize(s.stream);  // the kernel leaves on abort (or on its own time limit)
+        return SNAPPY_E_HIP;
+    }
+    std::vector<uint8_t> packed(n_files * 20);
+    if (n_files) {
+        uint64_t *d_off = static_cast<uint64_t *>(s.d_tables.ptr);
+        uint64_t *d_len = d_off + n_files;
+        SNAPPY_HIP_TRY(hipMemcpyAsync(packed.data(), d_digests, n_files * 20, hipMemcpyDeviceToHost, s.stream));
+        SNAPPY_HIP_TRY(hipStreamSynchronize(s.stream));
+        Sha1Arrival seen;
+        SNAPPY_HIP_TRY(hipMemcpy(&seen, d_arrival, sizeof(seen), hipMemcpyDeviceToHost));
+        if (seen.error) {
+            // The kernel stopped waiting; everything has been decoded since, so hash it in place.
+            st = enqueue_sha1_resident(lease, arena, d_off, d_len, n_files, d_digests, s.stream);
+            if (st != SNAPPY_OK)
+                return st;
+            SNAPPY_HIP_TRY(hipMemcpyAsync(packed.data(), d_digests, n_files * 20, hipMemcpyDeviceToHost, s.stream));
+            SNAPPY_HIP_TRY(hipStreamSynchronize(s.stream));
+        }
+        finish_sha1_profile(lease);
+    }
+    if (prof) {
+        // Decode kernel time of the call: the launches' own durations, added up.
+        float total_ms = 0.f;
+        for (const auto &run : launches) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, marks[2 * run.first], marks[2 * run.first + 1]) == hipSuccess)
+                total_ms += ms;
+            else
+                (void)hipGetLastError();
+        }
+        if (!launches.empty())
+            profile_store(1, total_ms);
+    }
+    return finish_overlapped(s, jobs, states, digests_out, order, first_row, ordered.size(), owner, packed);
+}
 
 // Decodes all archives, parses their headers and hashes every file body.
 // digests_out[a] holds 20 bytes per Files entry of archive a (zero when the
@@ -42,7 +446,13 @@ int import_batch(SlotLease &lease, std::vector<StreamJob> &jobs, std::vector<Arc
         batch_bytes += j.layout.decoded_size;
     lease.dev->work_units += n;
     lease.dev->work_bytes += batch_bytes;
-    int st = decode_streams_on_device(lease, jobs);
+    bool handled = false;
+    int st = import_batch_overlapped(lease, jobs, states, digests_out, &handled);
+    if (st != SNAPPY_OK || handled)
+        return st;
+    states.assign(n, ArchiveState());
+    digests_out.assign(n, std::vector<uint8_t>());
+    st = decode_streams_on_device(lease, jobs);
     if (st != SNAPPY_OK)
         return st;
 
@@ -54,32 +464,11 @@ int import_batch(SlotLease &lease, std::vector<StreamJob> &jobs, std::vector<Arc
         as.status = jobs[a].status;
         if (as.status != SNAPPY_OK)
             continue;
-        const uint64_t size = jobs[a].layout.decoded_size;
-        // Header: 9 bytes tell how much JSON follows.
-        uint8_t head[9] = {0};
-        const uint64_t head_len = size < 9 ? size : 9;
-        if (head_len)
-            SNAPPY_HIP_TRY(hipMemcpy(head, jobs[a].d_payload, head_len, hipMemcpyDeviceToHost));
-        uint64_t need = 0;
-        as.status = mcdf_header_extent(head, head_len, size, &need);
-        if (as.status != SNAPPY_OK)
-            continue;
-        std::vector<uint8_t> header(static_cast<size_t>(need));
-        SNAPPY_HIP_TRY(hipMemcpy(header.data(), jobs[a].d_payload, need, hipMemcpyDeviceToHost));
-        as.status = parse_mcdf_header(header.data(), need, as.info);
-        if (as.status != SNAPPY_OK)
-            continue;
-        as.status = mcdf_slice_files(as.info.files, as.info.body_offset, size, as.slices);
-        if (as.status != SNAPPY_OK)
-            continue;
-        digests_out[a].assign(as.slices.size() * 20, 0);
-        for (size_t f = 0; f < as.slices.size(); ++f) {
-            if (as.slices[f].status != SNAPPY_FILE_HASHED)
-                continue;
-            offsets.push_back(static_cast<uint64_t>(jobs[a].d_payload - arena) + as.slices[f].offset);
-            lengths.push_back(as.slices[f].length);
-            owner.emplace_back(a, f);
-        }
+        bool beyond = false;
+        st = header_and_slices(arena, jobs[a], a, jobs[a].layout.decoded_size, as, digests_out[a], offsets, lengths,
+                               owner, &beyond);
+        if (st != SNAPPY_OK)
+            return st;
     }
     if (!owner.empty()) {
         std::vector<uint8_t> packed(owner.size() * 20);

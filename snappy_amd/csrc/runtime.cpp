@@ -46,6 +46,9 @@ void destroy_slot(Slot &s)
     s.d_tables.release();
     s.d_out.release();
     s.d_misc.release();
+    s.d_chunks.release();
+    s.d_queues.release();
+    s.d_status.release();
     s.h_stage.release();
     s.h_ring.release();
     for (int k = 0; k < kProfileKernels; ++k)

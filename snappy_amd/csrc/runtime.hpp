@@ -74,6 +74,11 @@ struct Slot {
     Buffer d_tables;   // (offset, length) tables of a batch
     Buffer d_out;      // digests / statuses
     Buffer d_misc;     // queue counters, error words
+    // The LZ4 decoder's tables have buffers of their own: in an MCDF import the
+    // decoder and the SHA-1 kernels (which use the buffers above) run side by side.
+    Buffer d_chunks;   // Lz4Chunk[]
+    Buffer d_queues;   // one queue counter per decode launch
+    Buffer d_status;   // one status word per chunk
     Buffer h_stage;    // pinned host staging (tasks up, digests down)
     Buffer h_ring;     // pinned ring through which pageable sources travel to the device
     bool busy = false;

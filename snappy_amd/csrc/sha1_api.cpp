@@ -325,7 +325,26 @@ int hash_ranges_overlapped(SlotLease &lease, const HostRange *ranges, uint64_t f
     return SNAPPY_OK;
 }
 
+}  // namespace
+
+namespace {
 constexpr int kMaxHipDevices = 64;
+std::atomic<bool> g_waiting_kernel[kMaxHipDevices];
+}  // namespace
+
+WaitingKernelTurn::WaitingKernelTurn(int hip_device)
+    : flag_(&g_waiting_kernel[static_cast<unsigned>(hip_device) % kMaxHipDevices]),
+      mine_(!flag_->exchange(true))
+{
+}
+
+WaitingKernelTurn::~WaitingKernelTurn()
+{
+    if (mine_)
+        flag_->store(false);
+}
+
+namespace {
 
 // Copies the ranges [first, last) into the slot's device arena and hashes them
 // on the slot's device.
@@ -353,14 +372,9 @@ int hash_ranges_on_device(int device, const HostRange *ranges, uint64_t first, u
         return hash_ranges_serial(lease, ranges, first, n, digests, gate);
     // One waiting kernel per physical GPU at a time, for the same reason: a second
     // caller copies first and hashes afterwards.
-    static std::atomic<bool> waiting_kernel[kMaxHipDevices];
-    std::atomic<bool> &busy = waiting_kernel[lease.dev->hip_device % kMaxHipDevices];
-    if (busy.exchange(true))
+    WaitingKernelTurn turn(lease.dev->hip_device);
+    if (!turn.mine())
         return hash_ranges_serial(lease, ranges, first, n, digests, gate);
-    struct Release {
-        std::atomic<bool> &flag;
-        ~Release() { flag.store(false); }
-    } release{busy};
     return hash_ranges_overlapped(lease, ranges, first, n, slice, digests, gate);
 }
 

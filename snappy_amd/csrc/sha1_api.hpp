@@ -30,6 +30,24 @@ int enqueue_sha1_resident(SlotLease &lease, const uint8_t *d_base, const uint64_
                           hipStream_t stream, const uint32_t *d_epochs = nullptr,
                           Sha1Arrival *d_arrival = nullptr);
 
+// A kernel that waits for its input (an arrival counter raised by a transfer or by
+// another kernel) keeps one wave on every SIMD for as long as it runs.  Two of them
+// on one GPU would leave no room for the copy kernels and decoders they wait for,
+// so only one may run per physical GPU at a time: whoever does not get the turn
+// copies first and hashes afterwards.
+class WaitingKernelTurn {
+public:
+    explicit WaitingKernelTurn(int hip_device);
+    ~WaitingKernelTurn();
+    WaitingKernelTurn(const WaitingKernelTurn &) = delete;
+    WaitingKernelTurn &operator=(const WaitingKernelTurn &) = delete;
+    bool mine() const { return mine_; }
+
+private:
+    std::atomic<bool> *flag_;
+    bool mine_;
+};
+
 // After the stream has been synchronised: stores the kernels' event time for
 // snappy_profile_last_ms(0).
 void finish_sha1_profile(SlotLease &lease);

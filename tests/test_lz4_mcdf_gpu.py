@@ -369,3 +369,58 @@ def test_oversized_claims_do_not_take_the_batch_down(snappy, oracle, monkeypatch
     assert [r["status"] for r in whole] == [0, 0, 0]
     assert np.array_equal(whole[0]["digests"], res[0]["digests"])
     assert np.array_equal(whole[2]["digests"], res[2]["digests"])
+
+
+def test_mcdf_import_overlapped_path(snappy, oracle, monkeypatch):
+    """The import with copy, decode and hash overlapped (headers read from the archives' first
+    chunks, the SHA-1 kernel waiting for each archive's decode): forced on for small archives and
+    compared with the plain order of things and with the oracle.  Includes an archive whose later
+    chunk is malformed, one that is truncated, one with a bad header, an empty one, one whose first
+    chunk is stored, and a batch in which one header runs past its first chunk (handed back)."""
+    from snappy_amd.crypto import digests_to_hex
+
+    good = [_make_archive(oracle, 12 + 5 * k, 40 + k, chunk=1 << 16)[0] for k in range(4)]
+    bad_header = oracle.lz4net_encode(b"XCDF" + bytes(100), chunk_size=1 << 16)
+    # a flipped byte deep inside a later chunk's payload of random bytes would still decode; break a token instead
+    broken = bytearray(good[3])
+    st, size = oracle.lz4net_decoded_size(bytes(broken))
+    broken[len(broken) // 2: len(broken) // 2 + 64] = b"\xff" * 64
+    broken = bytes(broken)
+    stored_first = oracle.lz4net_encode(
+        oracle.build_mcdf_payload("stored", [(["a.tex"], H.random_bytes(150_000, 5), 150_000)]), chunk_size=1 << 16)
+    streams = [good[0], good[1][:-9], bad_header, good[2], b"", broken, stored_first, good[3]]
+
+    def expected(s):
+        try:
+            return oracle.mcdf_import(s), 0
+        except oracle.McdfError as e:
+            return None, e.code
+
+    def check(res, batch):
+        for s, r in zip(batch, res):
+            ref, want_status = expected(s)
+            assert r["status"] == want_status
+            if ref is None:
+                assert len(r["statuses"]) == 0
+                continue
+            assert list(r["statuses"]) == ref["statuses"]
+            hx = digests_to_hex(r["digests"])
+            for (paths, _), st_, h in zip(ref["data"]["Files"], ref["statuses"], hx):
+                if st_ == oracle.FILE_HASHED and paths:
+                    assert ref["map"][paths[0]] == h or h in ref["blobs"]
+
+    plain = snappy.mcdf_decode_and_hash_batch(streams)
+    check(plain, streams)
+    monkeypatch.setenv("SNAPPY_OVERLAP_MIN_BYTES", "0")
+    for _ in range(2):
+        over = snappy.mcdf_decode_and_hash_batch(streams)
+        check(over, streams)
+        for a, b in zip(plain, over):
+            assert a["status"] == b["status"] and np.array_equal(a["digests"], b["digests"])
+    single = snappy.mcdf_decode_and_hash(good[0], want_payload=True)
+    assert single["payload"] == oracle.mcdf_import(good[0])["payload"]
+    # 600 files, 4 KiB chunks: the header JSON is longer than the first chunk
+    many = [([f"chara/many/{i:04d}.mdl"], H.random_bytes(50 + i, i), 50 + i) for i in range(600)]
+    long_header = oracle.lz4net_encode(oracle.build_mcdf_payload("many", many), chunk_size=4096)
+    batch = [good[0], long_header]
+    check(snappy.mcdf_decode_and_hash_batch(batch), batch)
