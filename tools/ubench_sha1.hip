@@ -1,6 +1,14 @@
-// Micro-benchmark: SHA-1 compression ceiling on gfx950.
+// Micro-benchmark: SHA-1 compression ceiling on gfx950, and what staging through
+// LDS does to it (one message per lane, 64 per wave, equal sizes).
 //   mode 0: compress from registers, no memory traffic (pure VALU ceiling)
-//   mode 1: each lane streams its own contiguous message from HBM (64 B per block)
+//   mode 1: each lane streams its own contiguous message from HBM (64 B per block):
+//           the product's one-lane path without its prefetch
+//   mode 2: message blocks staged through LDS: the wave loads the next block of its
+//           64 messages with coalesced 16-byte loads (4 lanes per message), writes
+//           them to LDS, and every lane reads its own block back (4 x ds_read_b128)
+//   mode 3: message schedule staged in LDS: every lane expands W[0..79] + K of its
+//           block into LDS (80 dwords per lane, 20 KiB per wave), the 80 rounds read
+//           one word each (the classic "schedule in shared memory" form)
 // Reports GB/s of message bytes, wave-instructions per second and the shader
 // clock implied by s_memtime.  Build:
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I snappy_amd/csrc tools/ubench_sha1.hip -o tools/ubench_sha1
@@ -12,6 +20,30 @@
 #include "sha1_device.hpp"
 
 using namespace snappy;
+
+// Mode 2: a wave's 64 blocks of 64 bytes in LDS, rows padded to 80 bytes so that the
+// lanes' 16-byte reads fall on different banks.
+constexpr int kRowBytes = 80;
+
+__device__ __forceinline__ void stage_blocks(const uint8_t *wave_base, uint64_t stride, uint32_t b, uint8_t *lds,
+                                             uint32_t lane, uint4 (&v)[4])
+{
+    // Instruction q covers messages 16 q .. 16 q + 15; lane l reads 16 bytes of message 16 q + l / 4.
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint32_t msg = 16u * q + (lane >> 2);
+        v[q] = *reinterpret_cast<const uint4 *>(wave_base + msg * stride + uint64_t(b) * 64 + (lane & 3u) * 16u);
+    }
+}
+
+__device__ __forceinline__ void write_stage(uint8_t *lds, uint32_t lane, const uint4 (&v)[4])
+{
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint32_t msg = 16u * q + (lane >> 2);
+        *reinterpret_cast<uint4 *>(lds + msg * kRowBytes + (lane & 3u) * 16u) = v[q];
+    }
+}
 
 template <int MODE>
 __global__ void __launch_bounds__(256)
@@ -25,13 +57,54 @@ bench(const uint8_t *base, uint64_t stride, uint32_t blocks_per_lane, uint32_t *
     for (int k = 0; k < 16; ++k)
         w[k] = uint32_t(gid) * 2654435761u + k;
     const uint8_t *p = base + gid * stride;
+    __shared__ __attribute__((aligned(16))) uint8_t lds_blocks[MODE == 2 ? 4 * 64 * kRowBytes : 16];
+    __shared__ uint32_t lds_wk[MODE == 3 ? 2 * 80 * 64 : 4];  // mode 3 runs two waves per workgroup (40 KiB)
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint64_t t0 = __builtin_amdgcn_s_memtime();
-    for (uint32_t b = 0; b < blocks_per_lane; ++b) {
-        if (MODE == 1) {
+    if (MODE == 2) {
+        uint8_t *mine = lds_blocks + wave * 64 * kRowBytes;
+        const uint8_t *wave_base = base + (gid - lane) * stride;
+        uint4 v[4];
+        stage_blocks(wave_base, stride, 0, mine, lane, v);
+        for (uint32_t b = 0; b < blocks_per_lane; ++b) {
+            write_stage(mine, lane, v);
+            if (b + 1 < blocks_per_lane)
+                stage_blocks(wave_base, stride, b + 1, mine, lane, v);  // in flight during the rounds
+            uint32_t d[16];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint4 x = *reinterpret_cast<const uint4 *>(mine + lane * kRowBytes + q * 16);
+                d[4 * q] = x.x; d[4 * q + 1] = x.y; d[4 * q + 2] = x.z; d[4 * q + 3] = x.w;
+            }
+#pragma unroll
+            for (int t = 0; t < 16; ++t)
+                w[t] = __builtin_amdgcn_perm(d[t], d[t], 0x00010203u);
+            sha1_compress(h, w);
+        }
+    } else if (MODE == 3) {
+        uint32_t *wk = lds_wk + wave * 80 * 64;
+        for (uint32_t b = 0; b < blocks_per_lane; ++b) {
             load_block_be(p, w);
             p += 64;
+#pragma unroll
+            for (int t = 0; t < 80; ++t) {
+                const uint32_t wt = (t < 16) ? w[t] : sha1_schedule(w, t);
+                wk[t * 64 + lane] = wt + kSha1K[t / 20];
+            }
+            uint32_t a = h[0], bb = h[1], c = h[2], dd = h[3], e = h[4];
+#pragma unroll
+            for (int t = 0; t < 80; ++t)
+                sha1_round<true>(t, a, bb, c, dd, e, wk[t * 64 + lane]);
+            h[0] += a; h[1] += bb; h[2] += c; h[3] += dd; h[4] += e;
         }
-        sha1_compress(h, w);
+    } else {
+        for (uint32_t b = 0; b < blocks_per_lane; ++b) {
+            if (MODE == 1) {
+                load_block_be(p, w);
+                p += 64;
+            }
+            sha1_compress(h, w);
+        }
     }
     const uint64_t t1 = __builtin_amdgcn_s_memtime();
     sink[gid] = h[0] ^ h[1] ^ h[2] ^ h[3] ^ h[4];
@@ -42,7 +115,8 @@ bench(const uint8_t *base, uint64_t stride, uint32_t blocks_per_lane, uint32_t *
 template <int MODE>
 static void run(int blocks_per_cu, uint32_t blocks_per_lane, const uint8_t *d_data, uint64_t stride)
 {
-    const int grid = 256 * blocks_per_cu;
+    const int threads = MODE == 3 ? 128 : 256;
+    const int grid = 256 * blocks_per_cu * (256 / threads);
     uint32_t *d_sink;
     uint64_t *d_clk;
     (void)hipMalloc(&d_sink, size_t(grid) * 256 * 4);
@@ -50,16 +124,16 @@ static void run(int blocks_per_cu, uint32_t blocks_per_lane, const uint8_t *d_da
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0);
     (void)hipEventCreate(&e1);
-    hipLaunchKernelGGL(bench<MODE>, dim3(grid), dim3(256), 0, 0, d_data, stride, blocks_per_lane, d_sink, d_clk);
+    hipLaunchKernelGGL(bench<MODE>, dim3(grid), dim3(threads), 0, 0, d_data, stride, blocks_per_lane, d_sink, d_clk);
     (void)hipEventRecord(e0, 0);
-    hipLaunchKernelGGL(bench<MODE>, dim3(grid), dim3(256), 0, 0, d_data, stride, blocks_per_lane, d_sink, d_clk);
+    hipLaunchKernelGGL(bench<MODE>, dim3(grid), dim3(threads), 0, 0, d_data, stride, blocks_per_lane, d_sink, d_clk);
     (void)hipEventRecord(e1, 0);
     (void)hipEventSynchronize(e1);
     float ms = 0;
     (void)hipEventElapsedTime(&ms, e0, e1);
     uint64_t clk = 0;
     (void)hipMemcpy(&clk, d_clk, 8, hipMemcpyDeviceToHost);
-    const double bytes = double(grid) * 256 * blocks_per_lane * 64.0;
+    const double bytes = double(grid) * threads * blocks_per_lane * 64.0;
     const double waves = double(grid) * 4;
     printf("mode %d  waves/SIMD=%d  blocks/lane=%u  %.3f ms  %.1f GB/s  %.2f ns/block/wave  memtime ticks=%llu (%.3f GHz if ticks are cycles)\n",
            MODE, blocks_per_cu, blocks_per_lane, ms, bytes / ms / 1e6, ms * 1e6 / blocks_per_lane, (unsigned long long)clk,
@@ -81,5 +155,9 @@ int main()
         run<0>(w, 2048, d_data, stride);
     for (int w : {1, 2, 4, 8})
         run<1>(w, bpl, d_data, stride);
+    for (int w : {1, 2, 4})
+        run<2>(w, bpl, d_data, stride);
+    for (int w : {1, 2})
+        run<3>(w, bpl, d_data, stride);
     return 0;
 }
