@@ -333,6 +333,15 @@ float snappy_profile_last_ms(int kernel);
  * reference. */
 int snappy_sha1_last_plan(uint32_t path_end[4], double *planned_ms);
 
+/* The cost table the SHA-1 planner uses on `device`: per execution path (64, 16,
+ * 4 lanes per file, one lane per file) the nanoseconds a file's chain advances
+ * per 64-byte block and the SIMD time a block costs.  *measured (may be NULL) is
+ * 1 once the table's level has been set from this device's own chain time (the
+ * first hashing call measures it, about 7 ms once per device and process;
+ * SNAPPY_SHA1_CALIBRATE=0 keeps the built-in figures).  No counterpart in the
+ * reference. */
+int snappy_sha1_cost_model(int device, double chain_ns[4], double simd_ns[4], int *measured);
+
 #ifdef __cplusplus
 }
 #endif

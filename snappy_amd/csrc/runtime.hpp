@@ -90,6 +90,11 @@ struct DeviceCtx {
     // Host-pointer work this device has been given since it was bound (files or
     // archives, and their bytes): what snappy_device_work reports.
     std::atomic<uint64_t> work_units{0}, work_bytes{0};
+    // How this device's SHA-1 chain compares with the planner's table, measured the
+    // first time the device hashes (sha1_api.cpp); unused until cost_measured is set.
+    std::once_flag cost_once;
+    std::atomic<bool> cost_measured{false};
+    double chain_level = 1.0;
     std::mutex mu;
     std::condition_variable cv;
     std::vector<std::unique_ptr<Slot>> slots;

@@ -22,18 +22,30 @@ namespace snappy {
 
 namespace {
 
-// Measured cost model, used only to cut a batch into the kernel's paths (groups
-// of 64 / 16 / 4 / 1 lanes per message).  chain: nanoseconds a message spends
-// per 64-byte block when its wavefront has a SIMD to itself (one instruction
-// issues per ~4.2 cycles; 412 instructions per block on the chain plus the
-// schedule expansion shared by the group).  simd: SIMD time a block costs.
+// Cost model, used only to cut a batch into the kernel's paths (groups of 64 / 16
+// / 4 / 1 lanes per message).  chain: nanoseconds a message spends per 64-byte
+// block when its wavefront has a SIMD to itself (one instruction issues per ~4.2
+// cycles; 412 instructions per block on the chain plus the schedule expansion
+// shared by the group).  simd: SIMD time a block costs.
+//
+// The table is what one MI355X gave with the chip busy on each path.  Its ratios
+// follow from the paths' instruction counts and from how much the clock gives way
+// under each kind of load, and the cut is sensitive to them (with chain times
+// measured on an idle chip, 709 / 768 / 900 / 1190 ns, the mixed corpus took 302 ms
+// instead of 266: the largest files moved from 64 to 16 lanes each).  What differs
+// from box to box is the level, so that is what is measured: the 64-lane chain, one
+// message alone on the GPU at two sizes, the first time a device hashes (about 7 ms
+// once per device and process), and the whole table is scaled by what comes out
+// against kIdleChainNs.  SNAPPY_SHA1_CALIBRATE=0 switches the measurement off; a
+// result outside 0.6-1.6 times the expected one (a busy GPU) is not used.
+constexpr double kChainNs[kSha1Paths] = {723.0, 799.0, 985.0, 3000.0};
+constexpr double kSimdNs[kSha1Paths] = {723.0, 199.7, 61.6, 26.0};
+constexpr double kIdleChainNs = 709.0;  // the 64-lane chain on the same MI355X with nothing else running
 // The one-lane chain runs at 1300-1670 ns per block when the whole chip does
 // one-lane work, but next to wide-group waves on a mixed corpus files of 6-10 MB
 // were seen at up to ~2800 ns per block, and their waves then decided the
 // finishing time (270-440 ms per step instead of a steady 262 ms): the planner
 // is told the pessimistic figure, which sends such files to the 4-lane path.
-constexpr double kChainNs[kSha1Paths] = {723.0, 799.0, 985.0, 3000.0};
-constexpr double kSimdNs[kSha1Paths] = {723.0, 199.7, 61.6, 26.0};
 
 // How much slower chains run when all SIMDs are busy (the clock drops under load).
 constexpr double kLoadSlowdown = 0.45;
@@ -46,12 +58,14 @@ long env_long(const char *name, long fallback)
 
 }  // namespace
 
-Sha1CostModel sha1_cost_model(uint32_t n_simd, bool waits_for_transfer)
+Sha1CostModel sha1_cost_model(const DeviceCtx &dev, bool waits_for_transfer)
 {
+    const uint32_t n_simd = 4u * static_cast<uint32_t>(dev.n_cu);
     Sha1CostModel model;
+    const double level = dev.cost_measured.load(std::memory_order_acquire) ? dev.chain_level : 1.0;
     for (int k = 0; k < kSha1Paths; ++k) {
-        model.chain_ns[k] = kChainNs[k];
-        model.simd_ns[k] = kSimdNs[k];
+        model.chain_ns[k] = kChainNs[k] * level;
+        model.simd_ns[k] = kSimdNs[k] * level;
     }
     if (const char *v = std::getenv("SNAPPY_SHA1_CHAIN_NS"))  // tuning: "c0,c1,c2,c3"
         std::sscanf(v, "%lf,%lf,%lf,%lf", &model.chain_ns[0], &model.chain_ns[1], &model.chain_ns[2],
@@ -73,6 +87,75 @@ Sha1CostModel sha1_cost_model(uint32_t n_simd, bool waits_for_transfer)
     return model;
 }
 
+namespace {
+
+// One message on 64 lanes, alone on the GPU, at two sizes: the difference of the
+// two times over the difference in blocks is the chain time per block, free of
+// launch and planning overhead.  Runs on the slot's own stream with a temporary
+// buffer; failures leave the table in charge.
+void measure_chain_times(SlotLease &lease)
+{
+    DeviceCtx &dev = *lease.dev;
+    if (env_long("SNAPPY_SHA1_CALIBRATE", 1) == 0)
+        return;
+    constexpr uint64_t kBlocks[2] = {512, 2560};
+    constexpr size_t kDataBytes = kBlocks[1] * 64;
+    constexpr size_t kStateAt = (kDataBytes + 255) & ~size_t(255);
+    constexpr size_t kTaskAt = kStateAt + ((sizeof(Sha1PlanState) + 255) & ~size_t(255));
+    constexpr size_t kTablesAt = kTaskAt + 256;  // offset, length, digest
+    uint8_t *area = nullptr;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    auto done = [&] {
+        for (hipEvent_t e : ev)
+            if (e)
+                (void)hipEventDestroy(e);
+        if (area)
+            (void)hipFree(area);
+        (void)hipGetLastError();
+    };
+    if (hipMalloc(&area, kTablesAt + 256) != hipSuccess || hipEventCreate(&ev[0]) != hipSuccess ||
+        hipEventCreate(&ev[1]) != hipSuccess)
+        return done();
+    hipStream_t stream = lease.slot->stream;
+    Sha1PlanState *d_state = reinterpret_cast<Sha1PlanState *>(area + kStateAt);
+    Sha1Task *d_task = reinterpret_cast<Sha1Task *>(area + kTaskAt);
+    uint64_t *d_off = reinterpret_cast<uint64_t *>(area + kTablesAt);
+    uint64_t *d_len = d_off + 1;
+    uint8_t *d_digest = reinterpret_cast<uint8_t *>(d_off + 2);
+    if (hipMemsetAsync(area, 0x5A, kTablesAt + 256, stream) != hipSuccess ||
+        hipMemsetAsync(d_off, 0, 8, stream) != hipSuccess)
+        return done();
+    const uint32_t n_simd = 4u * static_cast<uint32_t>(dev.n_cu);
+    Sha1CostModel model = {};
+    for (int k = 0; k < kSha1Paths; ++k)
+        model.chain_ns[k] = model.simd_ns[k] = kChainNs[k];
+    model.n_simd = n_simd;
+    model.forced_waves = 1;
+    double measured = 0.0;
+    model.forced_path = 0;
+    for (int pass = 0; pass < 2; ++pass) {  // the first pass only brings the clock up
+        float ms[2] = {0.f, 0.f};
+        for (int size = 0; size < 2; ++size) {
+            const uint64_t len = kBlocks[size] * 64 - 9;  // pads to exactly kBlocks[size] blocks
+            if (hipMemcpyAsync(d_len, &len, sizeof len, hipMemcpyHostToDevice, stream) != hipSuccess ||
+                hipStreamSynchronize(stream) != hipSuccess || hipEventRecord(ev[0], stream) != hipSuccess ||
+                launch_sha1_plan(d_off, d_len, nullptr, 1, d_state, d_task, model, stream) != hipSuccess ||
+                launch_sha1_hop(area, d_task, d_state, d_digest, nullptr, 1, n_simd, 1, stream) != hipSuccess ||
+                hipEventRecord(ev[1], stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess ||
+                hipEventElapsedTime(&ms[size], ev[0], ev[1]) != hipSuccess)
+                return done();
+        }
+        measured = static_cast<double>(ms[1] - ms[0]) * 1e6 / static_cast<double>(kBlocks[1] - kBlocks[0]);
+    }
+    done();
+    if (!(measured > 0.6 * kIdleChainNs && measured < 1.6 * kIdleChainNs))
+        return;  // not a figure to plan with
+    dev.chain_level = measured / kIdleChainNs;
+    dev.cost_measured.store(true, std::memory_order_release);
+}
+
+}  // namespace
+
 int enqueue_sha1_resident(SlotLease &lease, const uint8_t *d_base, const uint64_t *d_offsets,
                           const uint64_t *d_lengths, uint64_t n, uint8_t *d_digests,
                           hipStream_t stream, const uint32_t *d_epochs, Sha1Arrival *d_arrival)
@@ -90,7 +173,8 @@ int enqueue_sha1_resident(SlotLease &lease, const uint8_t *d_base, const uint64_
     const uint32_t n32 = static_cast<uint32_t>(n);
     const uint32_t n_simd = 4u * static_cast<uint32_t>(lease.dev->n_cu);
 
-    const Sha1CostModel model = sha1_cost_model(n_simd, d_arrival != nullptr);
+    std::call_once(lease.dev->cost_once, [&] { measure_chain_times(lease); });
+    const Sha1CostModel model = sha1_cost_model(*lease.dev, d_arrival != nullptr);
 
     const bool prof = profiling_enabled();
     if (prof)
@@ -561,6 +645,23 @@ extern "C" int snappy_plan_shards_lpt(const uint64_t *lengths, uint64_t n, uint3
         if ((n && (!lengths || !shard_of)) || n_shards == 0)
             return SNAPPY_E_INVALID_ARG;
         plan_shards_lpt(lengths, n, n_shards, shard_of, shard_blocks);
+        return SNAPPY_OK;
+    });
+}
+
+extern "C" int snappy_sha1_cost_model(int device, double chain_ns[4], double simd_ns[4], int *measured)
+{
+    return abi_guard([&]() -> int {
+        DeviceCtx *dev = bound_device(device);
+        if (!dev || !chain_ns || !simd_ns)
+            return SNAPPY_E_INVALID_ARG;
+        const Sha1CostModel model = sha1_cost_model(*dev, false);
+        for (int k = 0; k < kSha1Paths; ++k) {
+            chain_ns[k] = model.chain_ns[k];
+            simd_ns[k] = model.simd_ns[k];
+        }
+        if (measured)
+            *measured = dev->cost_measured.load() ? 1 : 0;
         return SNAPPY_OK;
     });
 }

@@ -10,10 +10,11 @@
 
 namespace snappy {
 
-// The planner's measured cost table for a device with n_simd SIMDs, with the
-// tuning variables applied.  waits_for_transfer: the kernel will poll an arrival
-// counter, so only one wave per SIMD may stay.
-Sha1CostModel sha1_cost_model(uint32_t n_simd, bool waits_for_transfer);
+// The planner's cost table for a device (its own measured chain times once it has
+// hashed, one MI355X's otherwise), with the tuning variables applied.
+// waits_for_transfer: the kernel will poll an arrival counter, so only one wave
+// per SIMD may stay.
+Sha1CostModel sha1_cost_model(const DeviceCtx &dev, bool waits_for_transfer);
 
 // Looks up each bound device's copy of the file-scope planning area used by
 // snappy_sha1_batch_resident_noalloc (sha1_noalloc.hip).  Called by the

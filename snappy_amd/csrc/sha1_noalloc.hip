@@ -97,7 +97,7 @@ extern "C" int snappy_sha1_batch_resident_noalloc(int device, const void *d_base
         hipStream_t s = static_cast<hipStream_t>(stream);  // null: the device's default stream
         const uint32_t n32 = static_cast<uint32_t>(n);
         const uint32_t n_simd = 4u * static_cast<uint32_t>(dev->n_cu);
-        const Sha1CostModel model = sha1_cost_model(n_simd, false);
+        const Sha1CostModel model = sha1_cost_model(*dev, false);
 
         std::lock_guard<std::mutex> turn(g_scratch_mu[hip_device]);
         // The planner clears its header itself (the array still holds the last call's);

@@ -71,6 +71,8 @@ SYMBOLS = [
     ("snappy_lz4net_encode", _i, [_vp, _u64, ctypes.c_uint32, _vp, _u64, _u64p]),
     ("snappy_profile_enable", None, [_i]),
     ("snappy_profile_last_ms", ctypes.c_float, [_i]),
+    ("snappy_sha1_cost_model", _i, [_i, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
+                                    ctypes.POINTER(ctypes.c_int)]),
     ("snappy_sha1_last_plan", _i, [ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_double)]),
 ]
 

@@ -372,3 +372,24 @@ def test_single_message_calls_on_every_path(snappy):
             data = H.splitmix_bytes(n, 900 + n)
             assert snappy.get_hash(data) == hashlib.sha1(data).hexdigest().upper(), (path, n)
     force_path(None)
+
+
+def test_planner_cost_table_is_measured_on_the_device(snappy, oracle):
+    """The first hashing call measures the device's own chain time and scales the planner's table
+    by it; the table must stay plausible (ordered, near what one MI355X gave) and the digests
+    unaffected."""
+    import ctypes
+
+    L = snappy.native.lib()
+    blob = H.random_bytes(300_000, 3)
+    assert snappy.sha1(blob) == oracle.sha1(blob)
+    chain = (ctypes.c_double * 4)()
+    simd = (ctypes.c_double * 4)()
+    measured = ctypes.c_int(0)
+    snappy.native.check(L.snappy_sha1_cost_model(0, chain, simd, ctypes.byref(measured)), "cost model")
+    chain, simd = list(chain), list(simd)
+    assert measured.value == 1, (chain, simd)
+    assert chain[0] < chain[1] < chain[2] < chain[3]
+    assert simd[0] > simd[1] > simd[2] > simd[3]
+    for got, table in zip(chain, (723.0, 799.0, 985.0, 3000.0)):
+        assert 0.6 * table < got < 1.6 * table, chain
