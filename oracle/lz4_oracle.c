@@ -16,7 +16,7 @@
 #include <string.h>
 
 #define COPYLENGTH 8   /* r7x: a literal run ending in the last 8 bytes must end the block */
-#define LASTLITERALS 5 /* r7x: a match may not reach into the last 5 bytes */
+#define LASTLITERALS 5 /* encoder: the last 5 bytes are literals */
 #define MFLIMIT 12     /* encoder: no match starts in the last 12 bytes */
 #define MINMATCH 4
 
@@ -75,7 +75,13 @@ int oracle_lz4_block_decode(const uint8_t *in, uint64_t in_len, uint8_t *out, ui
         }
         mlen += MINMATCH;
         cpy = op + mlen;
-        if (cpy + LASTLITERALS > out_len)
+        /* r7x's tail branch, as recalled (UNVERIFIED, see snappy_oracle.h): a match is
+         * refused when it would write past the end ("cpy > oend") or end exactly at the
+         * end ("op == oend": the last bytes are supposed to be literals).  One that ends
+         * 1-4 bytes short of the end is accepted; the literal rule above then makes the
+         * next sequence end the block.  (Today's liblz4 refuses every match that reaches
+         * into the last 5 bytes; no compressor emits one.) */
+        if (cpy >= out_len)
             return ORACLE_E_LZ4_CORRUPT;
         /* Byte-serial copy: offset < mlen repeats the pattern. */
         for (uint64_t i = 0; i < mlen; ++i)

@@ -26,6 +26,23 @@
  *   - lz4net LZ4Stream chunk framing: restated from the published lz4net
  *     source as recalled; no copy of it is available offline, so for the
  *     FRAMING alone: PARITY UNPINNED.
+ *
+ * The assumptions nothing here can verify, in one place:
+ *   1. The chunk framing (varint flags, original length, compressed length when
+ *      flag bit 0 is set; passes in bits 2..; compressedLength > originalLength is
+ *      an error; a clean end only at a chunk boundary) is lz4net's as recalled.
+ *   2. The block decoder's acceptance of malformed input follows LZ4 r7x
+ *      LZ4_uncompress as recalled: a literal run ending within 8 bytes of the end
+ *      must end the block; a match is refused when it would write past the end or
+ *      end exactly at it, and accepted when it ends 1-4 bytes short (today's
+ *      liblz4 refuses those too).  Valid compressor output never meets either rule.
+ *   3. The MCDF header is read with a strict JSON reader.  Newtonsoft also takes
+ *      comments, single-quoted strings and unquoted names, and coerces a number or
+ *      bool given for a string property; those inputs are refused here
+ *      (E_MCDF_JSON).  A Files entry without GamePaths fails the header up front
+ *      (the reference fails when that file is reached); a JSON length beyond the
+ *      payload is E_MCDF_TRUNCATED (the reference's short ReadBytes then fails as
+ *      a JSON error).  Well-formed archives are unaffected.
  */
 #ifndef SNAPPY_ORACLE_H
 #define SNAPPY_ORACLE_H

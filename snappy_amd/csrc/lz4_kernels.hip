@@ -18,10 +18,10 @@
 // sequence per lane (take_batch below).
 //
 // Acceptance rules are those of the decoder lz4net ports (LZ4 r7x
-// LZ4_uncompress with a known output length): a literal run that ends within 8
-// bytes of the end must end the block exactly; a match must end at least 5
-// bytes before the end; consumed input must equal the chunk's compressed
-// length.  Every read and write is bounds-checked against the chunk, so a
+// LZ4_uncompress with a known output length, as recalled): a literal run that
+// ends within 8 bytes of the end must end the block exactly; a match must end
+// before the end of the block (not at it); consumed input must equal the chunk's
+// compressed length.  Every read and write is bounds-checked against the chunk, so a
 // corrupt stream yields a status word, never a stray access.
 #include "lz4_launch.hpp"
 #include "wave_util.hpp"
@@ -36,7 +36,6 @@ namespace {
 
 constexpr int kWave = 64;
 constexpr uint32_t kCopyLength = 8;
-constexpr uint32_t kLastLiterals = 5;
 
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 
@@ -887,7 +886,10 @@ __device__ bool decode_block(const uint8_t *__restrict__ in_base, uint64_t in_al
             }
         }
         ml += 4u;
-        if (ml > oend - op || op + ml + kLastLiterals > oend)
+        // r7x refuses a match that would write past the end or end exactly at it (the
+        // last bytes are supposed to be literals); one that ends 1-4 bytes short is taken,
+        // and the literal rule above makes the next sequence end the block.
+        if (ml >= oend - op)
             return false;
 
         if (ml <= kShortMatch && offset <= kHist - kShortMatch && op - offset >= valid_from) {

@@ -153,6 +153,15 @@ def good_block_vectors():
         "chained_overlap": block([(b"ab", 2, 6), (b"", 1, 5), (b"c", 4, 30), (b"", 9, 100),
                                   (b"12345", None, None)]),
     }
+    # A match that ends 1-4 bytes before the end of the block, followed by that many final
+    # literals.  No compressor writes this (the format asks for 5 final literals) and today's
+    # liblz4 refuses it; the decoder lz4net ports (LZ4 r7x LZ4_uncompress, as recalled: its
+    # tail branch only refuses "cpy > oend" and "op == oend") accepts it, and so do the oracle
+    # and the kernel.  UNVERIFIED against lz4net itself: these vectors make the choice explicit.
+    for tail in (1, 2, 3, 4):
+        vecs[f"match_ends_{tail}_before_end"] = block([(b"a", 1, 10), (b"wxyz"[:tail], None, None)])
+        vecs[f"long_match_ends_{tail}_before_end"] = block([(splitmix_bytes(40, 60 + tail), 33, 700),
+                                                            (b"wxyz"[:tail], None, None)])
     return vecs
 
 
@@ -160,7 +169,10 @@ def bad_block_vectors():
     """(block_bytes, claimed_output_len) pairs every conforming decoder must reject."""
     good, out = block([(b"a", 1, 10), (b"bcdef", None, None)])
     return {
-        "match_into_last5": (seq(b"a", 1, 10) + seq(b"bcde"), 15),
+        "match_ends_at_end": (seq(b"a", 1, 10), 11),                       # r7x: "op == oend" after a match
+        "match_ends_at_end_then_empty_literals": (seq(b"a", 1, 10) + seq(b""), 11),
+        "match_past_end": (seq(b"a", 1, 10) + seq(b"bcde"), 10),
+        "match_near_end_then_too_many_literals": (seq(b"a", 1, 10) + seq(b"bcdef"), 15),
         "literal_run_in_last8_not_at_end": (seq(b"0123456789", 4, 4) + seq(b"ab"), 16),
         "offset_zero": (seq(b"abcd", 0, 4) + seq(b"12345"), 13),
         "offset_before_start": (seq(b"abcd", 5, 4) + seq(b"12345"), 13),
