@@ -316,7 +316,11 @@ int import_batch_overlapped(SlotLease &lease, std::vector<StreamJob> &jobs, std:
         for (size_t k = 0; k < n_files; ++k)
             epochs[k] = epoch_of[owner[k].first];
         Sha1Arrival zero = {};
-        zero.max_idle_polls = 200000;  // ~10 s without progress before the kernel stops waiting
+        // ~1 s without progress before the kernel stops waiting.  Progress here is an archive's
+        // transfer and decode, tens of milliseconds; where kernels cannot run side by side (a
+        // profiler that serialises them) the decoder never starts, and the import should fall
+        // back to the plain order soon rather than after the transfers' own 10 s.
+        zero.max_idle_polls = 20000;
         if (const char *v = std::getenv("SNAPPY_ARRIVAL_MAX_POLLS"))
             zero.max_idle_polls = static_cast<uint32_t>(std::strtoul(v, nullptr, 10));
         SNAPPY_HIP_TRY(hipMemcpy(d_arrival, &zero, sizeof(zero), hipMemcpyHostToDevice));
