@@ -121,6 +121,27 @@ __device__ __forceinline__ void load_block_raw(const uint8_t *p, uint32_t shift,
     d[16] = q[shift ? 16 : 15];
 }
 
+// The first 16 of those dwords (four 16-byte loads), and the 17th alone.
+__device__ __forceinline__ void load_block_raw16(const uint8_t *p, uint32_t shift, uint32_t (&d)[17])
+{
+    const uint32_t *q = reinterpret_cast<const uint32_t *>(p - shift);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        uint32_t v[4];
+        __builtin_memcpy(v, q + 4 * i, 16);
+        d[4 * i] = v[0];
+        d[4 * i + 1] = v[1];
+        d[4 * i + 2] = v[2];
+        d[4 * i + 3] = v[3];
+    }
+}
+
+__device__ __forceinline__ uint32_t load_dword_after_block(const uint8_t *p, uint32_t shift)
+{
+    const uint32_t *q = reinterpret_cast<const uint32_t *>(p - shift);
+    return q[shift ? 16 : 15];
+}
+
 // Turns those dwords into the block's 16 big-endian words: one v_perm_b32 per
 // word does the byte swap and the sub-dword shift together.
 __device__ __forceinline__ void raw_block_to_be(const uint32_t (&d)[17], uint32_t shift,

@@ -200,21 +200,26 @@ __device__ __forceinline__ HopResult hop_once(const uint8_t *__restrict__ base,
 // runs over full blocks only, two per iteration with the raw words of the two
 // after them already on their way; the padding blocks follow once for the whole
 // wave (the messages of a wave are of similar size, so little is lost to lanes
-// that wait for the longest).
-__device__ __forceinline__ void compress_if(bool on, uint32_t (&h)[5], uint32_t (&w)[16])
+// that wait for the longest).  The loads of the loop are unconditional: a lane
+// with no block left reads `idle` (68 readable bytes that nobody writes) instead,
+// which keeps the raw words out of conditional code, where every iteration would
+// pay a register copy per word to carry the old values past the skipped load.
+// Smallest value of v over the wave's 64 lanes, in every lane.
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
 {
-    uint32_t moved[5] = {h[0], h[1], h[2], h[3], h[4]};
-    sha1_compress(moved, w);
 #pragma unroll
-    for (int k = 0; k < 5; ++k)
-        h[k] = on ? moved[k] : h[k];
+    for (int m = 32; m >= 1; m >>= 1) {
+        const uint32_t o = static_cast<uint32_t>(__shfl_xor(static_cast<int>(v), m, kWave));
+        v = o < v ? o : v;
+    }
+    return __builtin_amdgcn_readfirstlane(v);
 }
 
 __device__ __forceinline__ HopResult lanes_once(const uint8_t *__restrict__ base,
                                                 const Sha1Task *__restrict__ tasks, uint32_t first,
                                                 uint32_t end, uint32_t *queue,
                                                 uint8_t *__restrict__ digests, Sha1Arrival *arrival,
-                                                uint32_t lane)
+                                                const uint8_t *idle, uint32_t lane)
 {
     const uint32_t i0 = first + wave_claim(queue, kWave, lane);
     if (i0 >= end)
@@ -228,41 +233,71 @@ __device__ __forceinline__ HopResult lanes_once(const uint8_t *__restrict__ base
     const uint64_t n_full = len >> 6;
     const uint32_t rem = static_cast<uint32_t>(len & 63u);
     const uint32_t shift = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(msg) & 3u);
+    const uint8_t *rest = idle + shift;  // load_block_raw steps back by `shift` to the aligned dword
 
     uint32_t h[5];
 #pragma unroll
     for (int k = 0; k < 5; ++k)
         h[k] = kSha1Init[k];
     uint32_t even[17], odd[17];  // raw words of the next even-numbered and odd-numbered block
-#pragma unroll
-    for (int k = 0; k < 17; ++k)
-        even[k] = odd[k] = 0;
-    if (n_full > 0)
-        load_block_raw(msg, shift, even);
-    if (n_full > 1)
-        load_block_raw(msg + 64, shift, odd);
+    load_block_raw(n_full > 0 ? msg : rest, shift, even);
+    load_block_raw(n_full > 1 ? msg + 64 : rest, shift, odd);
 
     uint32_t w[16];
-    for (uint64_t blk = 0; __ballot(blk < n_full) != 0; blk += 2) {
+    uint64_t blk = 0;
+    // While every lane has this pair of blocks and the next, nothing in the loop
+    // depends on the lane: no masks, no selects, no copies of the state.  A block
+    // that does not start on a dword spills into a 17th dword, which is the first
+    // dword of the block after it: it is taken from there (for the odd block, once
+    // the next pair has arrived) rather than loaded, because what bounds this loop
+    // next to the arithmetic is the number of load instructions, not their size.
+    const uint64_t all_have = wave_min_u32(
+        have ? static_cast<uint32_t>(n_full < 0xFFFFFFFFull ? n_full : 0xFFFFFFFFull) : 0u);
+    if (blk + 3 < all_have) {
+        const uint32_t sel = be_selector(shift);
+        do {
+            uint32_t w2[16];
+            even[16] = odd[0];
+            raw_block_to_be(even, shift, w);
+#pragma unroll
+            for (int t = 0; t < 15; ++t)
+                w2[t] = __builtin_amdgcn_perm(odd[t + 1], odd[t], sel);
+            const uint32_t last = odd[15];
+            __builtin_amdgcn_sched_barrier(0);
+            load_block_raw16(msg + ((blk + 2) << 6), shift, even);
+            load_block_raw16(msg + ((blk + 3) << 6), shift, odd);
+            sha1_compress(h, w);
+            w2[15] = __builtin_amdgcn_perm(even[0], last, sel);
+            sha1_compress(h, w2);
+            blk += 2;
+        } while (blk + 3 < all_have);
+        // Back to the form the ragged loop keeps: 17 dwords per block.
+        even[16] = odd[0];
+        odd[16] = load_dword_after_block(blk + 1 < n_full ? msg + ((blk + 1) << 6) : rest, shift);
+    }
+    // The ragged rest, lane by lane.
+    for (; __ballot(blk < n_full) != 0; blk += 2) {
         // Both blocks of the next pair are asked for at once: the two halves of a
         // 128-byte line then arrive together instead of a block's time apart.
         uint32_t w2[16];
         raw_block_to_be(even, shift, w);
         raw_block_to_be(odd, shift, w2);
-        if (blk + 2 < n_full)
-            load_block_raw(msg + ((blk + 2) << 6), shift, even);
-        if (blk + 3 < n_full)
-            load_block_raw(msg + ((blk + 3) << 6), shift, odd);
-        compress_if(blk < n_full, h, w);
-        if (__ballot(blk + 1 < n_full) == 0)
-            break;
-        compress_if(blk + 1 < n_full, h, w2);
+        // The loads stay behind the byte swaps, so they can land in the registers
+        // the swaps have just read instead of in a second set that is copied over.
+        __builtin_amdgcn_sched_barrier(0);
+        load_block_raw(blk + 2 < n_full ? msg + ((blk + 2) << 6) : rest, shift, even);
+        load_block_raw(blk + 3 < n_full ? msg + ((blk + 3) << 6) : rest, shift, odd);
+        if (blk < n_full)
+            sha1_compress(h, w);
+        if (blk + 1 < n_full)
+            sha1_compress(h, w2);
     }
     const bool closed = load_tail_block_be(msg + (n_full << 6), rem, len, w);
-    compress_if(have, h, w);
-    if (__ballot(have && !closed) != 0) {
+    if (have)
+        sha1_compress(h, w);
+    if (have && !closed) {
         make_length_block(len, w);
-        compress_if(have && !closed, h, w);
+        sha1_compress(h, w);
     }
     if (have)
         store_digest(digests + 20ull * task.out_index, h);
@@ -321,7 +356,10 @@ sha1_hop_kernel(const uint8_t *__restrict__ base, const Sha1Task *__restrict__ t
         case 0: r = hop_once<64>(base, tasks, lo[0], hi[0], &state->queue[0].next, digests, arrival, lane); break;
         case 1: r = hop_once<16>(base, tasks, lo[1], hi[1], &state->queue[1].next, digests, arrival, lane); break;
         case 2: r = hop_once<4>(base, tasks, lo[2], hi[2], &state->queue[2].next, digests, arrival, lane); break;
-        default: r = lanes_once(base, tasks, lo[3], hi[3], &state->queue[3].next, digests, arrival, lane); break;
+        default:
+            r = lanes_once(base, tasks, lo[3], hi[3], &state->queue[3].next, digests, arrival,
+                           reinterpret_cast<const uint8_t *>(state->blocks), lane);
+            break;
         }
         if (r == kHopGiveUp)
             break;

@@ -6,6 +6,12 @@
 //   mode 2: message blocks staged through LDS: the wave loads the next block of its
 //           64 messages with coalesced 16-byte loads (4 lanes per message), writes
 //           them to LDS, and every lane reads its own block back (4 x ds_read_b128)
+//   mode 4: as mode 1 with four 16-byte loads per block (mode 1 issues a fifth, 4-byte one for
+//           messages that do not start on a dword); mode 5: sixteen 4-byte loads per block.
+//           Together they show what a lane's load request costs whatever its size.
+//   mode 6: the loads of mode 4 regrouped so that the four lanes of a quad read the 64 bytes
+//           of one message's block together (the words land in the wrong lanes: this measures
+//           the loads only, not a usable hash)
 //   mode 3: message schedule staged in LDS: every lane expands W[0..79] + K of its
 //           block into LDS (80 dwords per lane, 20 KiB per wave), the 80 rounds read
 //           one word each (the classic "schedule in shared memory" form)
@@ -60,6 +66,7 @@ bench(const uint8_t *base, uint64_t stride, uint32_t blocks_per_lane, uint32_t *
     __shared__ __attribute__((aligned(16))) uint8_t lds_blocks[MODE == 2 ? 4 * 64 * kRowBytes : 16];
     __shared__ uint32_t lds_wk[MODE == 3 ? 2 * 80 * 64 : 4];  // mode 3 runs two waves per workgroup (40 KiB)
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint64_t r0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz, whatever the shader clock does
     const uint64_t t0 = __builtin_amdgcn_s_memtime();
     if (MODE == 2) {
         uint8_t *mine = lds_blocks + wave * 64 * kRowBytes;
@@ -103,13 +110,49 @@ bench(const uint8_t *base, uint64_t stride, uint32_t blocks_per_lane, uint32_t *
                 load_block_be(p, w);
                 p += 64;
             }
+            if (MODE == 4) {  // four 16-byte requests per block and lane instead of mode 1's five
+                const uint4 *q = reinterpret_cast<const uint4 *>(p);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const uint4 x = q[i];
+                    w[4 * i] = __builtin_amdgcn_perm(x.x, x.x, 0x00010203u);
+                    w[4 * i + 1] = __builtin_amdgcn_perm(x.y, x.y, 0x00010203u);
+                    w[4 * i + 2] = __builtin_amdgcn_perm(x.z, x.z, 0x00010203u);
+                    w[4 * i + 3] = __builtin_amdgcn_perm(x.w, x.w, 0x00010203u);
+                }
+                p += 64;
+            }
+            if (MODE == 6) {  // the four lanes of a quad read one message's block together, four messages in turn
+                const uint32_t ln = threadIdx.x & 63u;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const uint8_t *m = base + (gid - (ln & 3u) + i) * stride + uint64_t(b) * 64 + (ln & 3u) * 16u;
+                    const uint4 x = *reinterpret_cast<const uint4 *>(m);
+                    w[4 * i] = __builtin_amdgcn_perm(x.x, x.x, 0x00010203u);
+                    w[4 * i + 1] = __builtin_amdgcn_perm(x.y, x.y, 0x00010203u);
+                    w[4 * i + 2] = __builtin_amdgcn_perm(x.z, x.z, 0x00010203u);
+                    w[4 * i + 3] = __builtin_amdgcn_perm(x.w, x.w, 0x00010203u);
+                }
+            }
+            if (MODE == 5) {  // sixteen 4-byte requests per block and lane
+                const volatile uint32_t *q = reinterpret_cast<const volatile uint32_t *>(p);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const uint32_t x = q[i];
+                    w[i] = __builtin_amdgcn_perm(x, x, 0x00010203u);
+                }
+                p += 64;
+            }
             sha1_compress(h, w);
         }
     }
     const uint64_t t1 = __builtin_amdgcn_s_memtime();
+    const uint64_t r1 = __builtin_amdgcn_s_memrealtime();
     sink[gid] = h[0] ^ h[1] ^ h[2] ^ h[3] ^ h[4];
-    if (gid == 0)
-        *clk = t1 - t0;
+    if (gid == 0) {
+        clk[0] = t1 - t0;
+        clk[1] = r1 - r0;
+    }
 }
 
 template <int MODE>
@@ -120,7 +163,7 @@ static void run(int blocks_per_cu, uint32_t blocks_per_lane, const uint8_t *d_da
     uint32_t *d_sink;
     uint64_t *d_clk;
     (void)hipMalloc(&d_sink, size_t(grid) * 256 * 4);
-    (void)hipMalloc(&d_clk, 8);
+    (void)hipMalloc(&d_clk, 16);
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0);
     (void)hipEventCreate(&e1);
@@ -131,13 +174,15 @@ static void run(int blocks_per_cu, uint32_t blocks_per_lane, const uint8_t *d_da
     (void)hipEventSynchronize(e1);
     float ms = 0;
     (void)hipEventElapsedTime(&ms, e0, e1);
-    uint64_t clk = 0;
-    (void)hipMemcpy(&clk, d_clk, 8, hipMemcpyDeviceToHost);
+    uint64_t clks[2] = {0, 0};
+    (void)hipMemcpy(clks, d_clk, 16, hipMemcpyDeviceToHost);
+    const uint64_t clk = clks[0];
     const double bytes = double(grid) * threads * blocks_per_lane * 64.0;
     const double waves = double(grid) * 4;
-    printf("mode %d  waves/SIMD=%d  blocks/lane=%u  %.3f ms  %.1f GB/s  %.2f ns/block/wave  memtime ticks=%llu (%.3f GHz if ticks are cycles)\n",
+    printf("mode %d  waves/SIMD=%d  blocks/lane=%u  %.3f ms  %.1f GB/s  %.2f ns/block/wave  memtime ticks=%llu (%.3f GHz if ticks are cycles)  wave 0: %llu memtime ticks in %llu ticks of 10 ns = %.3f ticks/ns\n",
            MODE, blocks_per_cu, blocks_per_lane, ms, bytes / ms / 1e6, ms * 1e6 / blocks_per_lane, (unsigned long long)clk,
-           double(clk) / (ms * 1e6));
+           double(clk) / (ms * 1e6), (unsigned long long)clks[0], (unsigned long long)clks[1],
+           clks[1] ? double(clks[0]) / (10.0 * double(clks[1])) : 0.0);
     (void)waves;
     (void)hipFree(d_sink);
     (void)hipFree(d_clk);
@@ -155,6 +200,12 @@ int main()
         run<0>(w, 2048, d_data, stride);
     for (int w : {1, 2, 4, 8})
         run<1>(w, bpl, d_data, stride);
+    for (int w : {1, 2, 4, 8})
+        run<4>(w, bpl, d_data, stride);
+    for (int w : {2, 4})
+        run<5>(w, bpl, d_data, stride);
+    for (int w : {1, 2, 4, 8})
+        run<6>(w, bpl, d_data, stride);
     for (int w : {1, 2, 4})
         run<2>(w, bpl, d_data, stride);
     for (int w : {1, 2})
