@@ -12,6 +12,7 @@
 //   mode 6: the loads of mode 4 regrouped so that the four lanes of a quad read the 64 bytes
 //           of one message's block together (the words land in the wrong lanes: this measures
 //           the loads only, not a usable hash)
+//   modes 7-9: mode 0 with 16, 32 or 1 of the 64 lanes enabled (does a partly disabled wave issue faster? no)
 //   mode 3: message schedule staged in LDS: every lane expands W[0..79] + K of its
 //           block into LDS (80 dwords per lane, 20 KiB per wave), the 80 rounds read
 //           one word each (the classic "schedule in shared memory" form)
@@ -103,6 +104,14 @@ bench(const uint8_t *base, uint64_t stride, uint32_t blocks_per_lane, uint32_t *
             for (int t = 0; t < 80; ++t)
                 sha1_round<true>(t, a, bb, c, dd, e, wk[t * 64 + lane]);
             h[0] += a; h[1] += bb; h[2] += c; h[3] += dd; h[4] += e;
+        }
+    } else if (MODE == 7 || MODE == 8 || MODE == 9) {
+        // Registers only, with 16 (mode 7), 32 (mode 8) or 1 (mode 9) of the 64 lanes enabled:
+        // does a wave's instruction take fewer than four passes when whole quarters of it are off?
+        const uint32_t on = MODE == 7 ? 16u : MODE == 8 ? 32u : 1u;
+        if (lane < on) {
+            for (uint32_t b = 0; b < blocks_per_lane; ++b)
+                sha1_compress(h, w);
         }
     } else {
         for (uint32_t b = 0; b < blocks_per_lane; ++b) {
@@ -198,6 +207,9 @@ int main()
     (void)hipMemset(d_data, 0x5A, bytes);
     for (int w : {1, 2, 4, 8})
         run<0>(w, 2048, d_data, stride);
+    run<7>(1, 2048, d_data, stride);
+    run<8>(1, 2048, d_data, stride);
+    run<9>(1, 2048, d_data, stride);
     for (int w : {1, 2, 4, 8})
         run<1>(w, bpl, d_data, stride);
     for (int w : {1, 2, 4, 8})
