@@ -12,6 +12,9 @@
 //   mode 6: the loads of mode 4 regrouped so that the four lanes of a quad read the 64 bytes
 //           of one message's block together (the words land in the wrong lanes: this measures
 //           the loads only, not a usable hash)
+//   modes 12, 13: mode 4 with four or two blocks (256 or 128 contiguous bytes) loaded per lane at a time
+//   mode 11: mode 6 with non-temporal loads (no L1 allocation)
+//   mode 10: mode 4 with each block's first load issued two blocks ahead of its other three
 //   modes 7-9: mode 0 with 16, 32 or 1 of the 64 lanes enabled (does a partly disabled wave issue faster? no)
 //   mode 3: message schedule staged in LDS: every lane expands W[0..79] + K of its
 //           block into LDS (80 dwords per lane, 20 KiB per wave), the 80 rounds read
@@ -105,6 +108,47 @@ bench(const uint8_t *base, uint64_t stride, uint32_t blocks_per_lane, uint32_t *
                 sha1_round<true>(t, a, bb, c, dd, e, wk[t * 64 + lane]);
             h[0] += a; h[1] += bb; h[2] += c; h[3] += dd; h[4] += e;
         }
+    } else if (MODE == 12 || MODE == 13) {
+        // Mode 4 with 256 (mode 12) or 128 (mode 13) contiguous bytes asked for per lane and visit:
+        // does the memory side like longer bursts per stream?
+        constexpr int kBlocks = MODE == 12 ? 4 : 2;
+        const uint4 *q = reinterpret_cast<const uint4 *>(p);
+        for (uint32_t b = 0; b + kBlocks <= blocks_per_lane; b += kBlocks) {
+            uint4 x[4 * kBlocks];
+#pragma unroll
+            for (int i = 0; i < 4 * kBlocks; ++i)
+                x[i] = q[4 * b + i];
+#pragma unroll
+            for (int k = 0; k < kBlocks; ++k) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    w[4 * i] = __builtin_amdgcn_perm(x[4 * k + i].x, x[4 * k + i].x, 0x00010203u);
+                    w[4 * i + 1] = __builtin_amdgcn_perm(x[4 * k + i].y, x[4 * k + i].y, 0x00010203u);
+                    w[4 * i + 2] = __builtin_amdgcn_perm(x[4 * k + i].z, x[4 * k + i].z, 0x00010203u);
+                    w[4 * i + 3] = __builtin_amdgcn_perm(x[4 * k + i].w, x[4 * k + i].w, 0x00010203u);
+                }
+                sha1_compress(h, w);
+            }
+        }
+    } else if (MODE == 10) {
+        // Mode 4 with the first 16 bytes of every block asked for two blocks ahead, so that the
+        // three loads that follow into the same 64 bytes find them in L1 instead of on their way.
+        const uint4 *q = reinterpret_cast<const uint4 *>(p);
+        uint4 a0 = q[0], a1 = q[4];
+        for (uint32_t b = 0; b < blocks_per_lane; ++b) {
+            const uint4 x0 = a0;
+            a0 = a1;
+            a1 = q[4 * (b + 2 < blocks_per_lane ? b + 2 : b)];
+            const uint4 x[4] = {x0, q[4 * b + 1], q[4 * b + 2], q[4 * b + 3]};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                w[4 * i] = __builtin_amdgcn_perm(x[i].x, x[i].x, 0x00010203u);
+                w[4 * i + 1] = __builtin_amdgcn_perm(x[i].y, x[i].y, 0x00010203u);
+                w[4 * i + 2] = __builtin_amdgcn_perm(x[i].z, x[i].z, 0x00010203u);
+                w[4 * i + 3] = __builtin_amdgcn_perm(x[i].w, x[i].w, 0x00010203u);
+            }
+            sha1_compress(h, w);
+        }
     } else if (MODE == 7 || MODE == 8 || MODE == 9) {
         // Registers only, with 16 (mode 7), 32 (mode 8) or 1 (mode 9) of the 64 lanes enabled:
         // does a wave's instruction take fewer than four passes when whole quarters of it are off?
@@ -131,12 +175,19 @@ bench(const uint8_t *base, uint64_t stride, uint32_t blocks_per_lane, uint32_t *
                 }
                 p += 64;
             }
-            if (MODE == 6) {  // the four lanes of a quad read one message's block together, four messages in turn
+            if (MODE == 6 || MODE == 11) {  // the four lanes of a quad read one message's block together, four messages in turn
                 const uint32_t ln = threadIdx.x & 63u;
+                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const uint8_t *m = base + (gid - (ln & 3u) + i) * stride + uint64_t(b) * 64 + (ln & 3u) * 16u;
-                    const uint4 x = *reinterpret_cast<const uint4 *>(m);
+                    uint4 x;
+                    if (MODE == 11) {  // past L1: the quad's 64 bytes are one request to L2
+                        const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(m));
+                        x = make_uint4(v.x, v.y, v.z, v.w);
+                    } else {
+                        x = *reinterpret_cast<const uint4 *>(m);
+                    }
                     w[4 * i] = __builtin_amdgcn_perm(x.x, x.x, 0x00010203u);
                     w[4 * i + 1] = __builtin_amdgcn_perm(x.y, x.y, 0x00010203u);
                     w[4 * i + 2] = __builtin_amdgcn_perm(x.z, x.z, 0x00010203u);
@@ -197,8 +248,15 @@ static void run(int blocks_per_cu, uint32_t blocks_per_lane, const uint8_t *d_da
     (void)hipFree(d_clk);
 }
 
-int main()
+int main(int argc, char **argv)
 {
+    if (argc > 1 && argv[1][0] == 's') {
+        // Sustained load: the register-only mode back to back for about half a second, to see
+        // whether the clock (and with it the ceiling) holds beyond a few milliseconds.
+        for (int rep = 0; rep < 30; ++rep)
+            run<0>(8, 2048, nullptr, 0);
+        return 0;
+    }
     const uint64_t stride = 20000;  // bytes between lanes' messages (mode 1)
     const uint32_t bpl = 256;
     uint8_t *d_data;
@@ -214,10 +272,18 @@ int main()
         run<1>(w, bpl, d_data, stride);
     for (int w : {1, 2, 4, 8})
         run<4>(w, bpl, d_data, stride);
+    for (int w : {1, 2, 4, 8})
+        run<10>(w, bpl, d_data, stride);
+    for (int w : {1, 2, 4})
+        run<13>(w, bpl, d_data, stride);
+    for (int w : {1, 2, 4})
+        run<12>(w, bpl, d_data, stride);
     for (int w : {2, 4})
         run<5>(w, bpl, d_data, stride);
     for (int w : {1, 2, 4, 8})
         run<6>(w, bpl, d_data, stride);
+    for (int w : {1, 2, 4, 8})
+        run<11>(w, bpl, d_data, stride);
     for (int w : {1, 2, 4})
         run<2>(w, bpl, d_data, stride);
     for (int w : {1, 2})
