@@ -62,6 +62,9 @@ struct InputWindow {
     uint32_t stage_count;     // uniform: blocks staged
     uint32_t first;           // uniform: number of the dword held by lane 0
     uint32_t a;               // per lane: dword first + lane
+    uint32_t lens;            // per lane: see token_lengths(); belongs to the window at lens_first
+    uint32_t lens_first;      // uniform
+    uint32_t lens_limit;      // uniform: the limit the table was made for
 
     // Every wait is placed here, on the paths that move the window.  A wait left
     // to the compiler lands where the paths join again, is executed by every
@@ -121,6 +124,39 @@ struct InputWindow {
     {
         restage(0, false, lane);
         slide(0, lane);
+        lens_first = 0xFFFFFFFFu;
+    }
+
+    // For each of the lane's four byte positions: how far the next token is if a
+    // token starts there and its sequence is one the batches take (a literal run
+    // with at most one length-extension byte, a match with at most one), one
+    // byte per position; 0 where that cannot be said (a longer extension, or a
+    // distance that does not fit a byte) and for positions past `limit`, the last
+    // one a batch's sequence may start at.  It takes the token and the byte behind
+    // it, nothing else, so all 256 positions of the window are done side by side
+    // and the serial walk from token to token is left with one v_readlane and a
+    // few scalar operations per token.  Lane 63's last position looks at a byte
+    // outside the window; the walk moves the window before it gets there.
+    __device__ __forceinline__ void token_lengths(uint32_t limit, uint32_t lane)
+    {
+        // The dword of the lane above (wave_shl:1; lane 63 keeps 0).
+        const uint32_t next =
+            static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(a), 0x130, 0xF, 0xF, false));
+        const uint32_t p0 = (first + lane) * 4u;
+        uint32_t packed = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k) {
+            const uint32_t t = (a >> (8u * k)) & 255u;
+            const uint32_t nb = (k < 3u ? a >> (8u * k + 8u) : next) & 255u;
+            const uint32_t lit = t >> 4;
+            uint32_t len = 3u + lit + ((t & 15u) == 15u ? 1u : 0u);
+            len += lit == 15u ? 1u + nb : 0u;
+            len = (lit == 15u && nb >= 236u) || p0 + k > limit ? 0u : len;  // 3 + 15 + 1 + 1 + 236 = 256
+            packed |= len << (8u * k);
+        }
+        lens = packed;
+        lens_first = first;
+        lens_limit = limit;
     }
 
     // The four bytes at byte position `pos` (counted from `aligned`), little-endian.
@@ -452,20 +488,37 @@ constexpr uint32_t kBatchInput = 512;   // staged bytes a sequence may touch fro
 constexpr uint32_t kLitStep = 8;        // dwords a lane has in flight per step when copying literals
 constexpr uint32_t kMatchStep = 4;      // and matches: a match may repeat a pattern of 16 bytes or more
 
-// The first `count` (at most 4 count) bytes of `w` go to output position `pos`
-// and to the ring.
-__device__ __forceinline__ void put_exact(uint8_t *dst, uint8_t *ring, uint32_t pos, uint32_t w,
-                                          uint32_t count)
+// The first `count` (at most 4 count) bytes of `w` go to output position `pos` of
+// the ring: a batch's output goes to memory in one piece at its end.
+__device__ __forceinline__ void put_ring(uint8_t *ring, uint32_t pos, uint32_t w, uint32_t count)
 {
     if (count >= 4u) {
-        store32(dst + pos, w);
         ring_write32(ring, pos, w);
     } else {
-        for (uint32_t q = 0; q < count; ++q) {
-            const uint8_t byte = static_cast<uint8_t>(w >> (8u * q));
-            dst[pos + q] = byte;
-            ring[(pos + q) & (kHist - 1u)] = byte;
-        }
+        for (uint32_t q = 0; q < count; ++q)
+            ring[(pos + q) & (kHist - 1u)] = static_cast<uint8_t>(w >> (8u * q));
+    }
+}
+
+// Output positions [beg, end), which the ring holds, go to memory: 16 bytes per lane
+// and step, consecutive lanes on consecutive pieces, instead of the scattered
+// dword stores a sequence per lane would make.  Pieces lie on multiples of 16
+// in output position (and so in the ring); the bytes before the first whole piece
+// and behind the last are stored one per lane.
+__device__ __forceinline__ void flush_ring(uint8_t *dst, const uint8_t *ring, uint32_t beg, uint32_t end,
+                                           uint32_t lane)
+{
+    const uint32_t up = (beg + 15u) & ~15u;
+    const uint32_t head_end = up < end ? up : end;
+    const uint32_t down = end & ~15u;
+    const uint32_t tail_beg = down > head_end ? down : head_end;
+    if (lane < head_end - beg)
+        dst[beg + lane] = ring[(beg + lane) & (kHist - 1u)];
+    if (lane < end - tail_beg)
+        dst[tail_beg + lane] = ring[(tail_beg + lane) & (kHist - 1u)];
+    for (uint32_t p = head_end + 16u * lane; p < tail_beg; p += 16u * kWave) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(ring + (p & (kHist - 1u)));
+        __builtin_memcpy(dst + p, &v, 16);
     }
 }
 
@@ -483,91 +536,19 @@ __device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v)
     return v;
 }
 
-// Where the tokens of the next sequences start, for up to 64 sequences at once.
-// Followed one after the other, each start costs a dependent chain through both
-// units (v_readlane -> scalar arithmetic -> the next v_readlane's lane number),
-// some 290 clocks per token.  Here every byte position p of a window of
-// kWalkWindow input bytes is given next(p), the start of the following token if
-// a token started at p (that takes the token and the byte behind it, nothing
-// else), and the table is then composed with itself: after k rounds it holds
-// next^(2^k).  Lane j reaches next^j(0) by applying the tables of the set bits of
-// j as they come by, so sequence j's start is known after six rounds of table
-// look-ups that all lanes do side by side, with no serial step at all.
-// Positions past the window (or past `last`, the last position a sequence may
-// start at) are the sentinel, which maps to itself.
-constexpr uint32_t kWalkWindow = 1024;
-constexpr uint32_t kWalkSentinel = kWalkWindow;
-constexpr uint32_t kWalkTable = kWalkWindow + 64u;  // uint16_t entries per table; two tables per wave
-constexpr uint32_t kWalkPerLane = kWalkWindow / kWave;
-
-// Returns the number of starts found (at least 1); lane j < that number gets
-// sequence j's start, relative to `bytes`, in `rel`.
-__device__ __forceinline__ uint32_t find_token_starts(const uint8_t *bytes, uint16_t *jump, uint32_t last,
-                                                      uint32_t lane, uint32_t &rel)
-{
-    uint16_t *tab = jump, *other = jump + kWalkTable;
-    // All reads first, then the arithmetic, then the writes: each group is issued
-    // back to back and waited for once.
-    uint32_t t[kWalkPerLane];
-#pragma unroll
-    for (uint32_t q = 0; q < kWalkPerLane; ++q) {
-        uint16_t two;
-        __builtin_memcpy(&two, bytes + q * kWave + lane, 2);  // the token and the byte behind it
-        t[q] = two;
-    }
-#pragma unroll
-    for (uint32_t q = 0; q < kWalkPerLane; ++q) {
-        const uint32_t p = q * kWave + lane;
-        const uint32_t r = t[q];
-        const uint32_t lit = (r >> 4) & 15u;
-        uint32_t nx = p + 3u + lit + ((r & 15u) == 15u ? 1u : 0u);
-        nx += lit == 15u ? 1u + (r >> 8) : 0u;
-        // nx > p, so one comparison covers both the start and its successor
-        t[q] = nx > last ? kWalkSentinel : nx;
-    }
-#pragma unroll
-    for (uint32_t q = 0; q < kWalkPerLane; ++q)
-        tab[q * kWave + lane] = static_cast<uint16_t>(t[q]);
-    tab[kWalkSentinel + lane] = static_cast<uint16_t>(kWalkSentinel);
-    other[kWalkSentinel + lane] = static_cast<uint16_t>(kWalkSentinel);
-    uint32_t cur = 0;
-#pragma unroll
-    for (uint32_t k = 0; k < 6u; ++k) {
-        if ((lane >> k) & 1u)
-            cur = tab[cur];
-        if (k == 5u)
-            break;
-#pragma unroll
-        for (uint32_t q = 0; q < kWalkPerLane; ++q)
-            t[q] = tab[q * kWave + lane];
-#pragma unroll
-        for (uint32_t q = 0; q < kWalkPerLane; ++q)
-            t[q] = tab[t[q]];
-#pragma unroll
-        for (uint32_t q = 0; q < kWalkPerLane; ++q)
-            other[q * kWave + lane] = static_cast<uint16_t>(t[q]);
-        uint16_t *swap = tab;
-        tab = other;
-        other = swap;
-    }
-    rel = cur;
-    const uint64_t beyond = __builtin_amdgcn_ballot_w64(cur >= kWalkSentinel);
-    return beyond ? static_cast<uint32_t>(__builtin_ctzll(beyond)) : kWave;
-}
-
 // Returns the number of sequences taken.  `walk` is how many tokens the next call
 // should look at: a stream of sequences that are not for this code should not pay
 // for 64 tokens walked in vain each time.
-__device__ __forceinline__ uint32_t take_batch(InputWindow &win, uint8_t *dst, uint8_t *ring, uint16_t *jump,
+__device__ __forceinline__ uint32_t take_batch(InputWindow &win, uint8_t *dst, uint8_t *ring,
                                                uint32_t &ip_io, uint32_t &op_io, uint32_t valid_from,
-                                               uint32_t iend, uint32_t oend, uint32_t &walk, bool &short_tokens,
+                                               uint32_t iend, uint32_t oend, uint32_t &walk,
                                                uint32_t lane, uint32_t tuning, PhaseClock &clk)
 {
     PHASE_MARK(clk, 5);
     uint32_t ip = ip_io;  // uniform
     const uint32_t start = op_io;
     const bool likely = walk >= 16u;  // recent batches were worth their while
-    const uint32_t ahead = likely ? (short_tokens ? kWalkWindow : 3u * kBatchInput) : 0u;
+    const uint32_t ahead = likely ? 3u * kBatchInput : 0u;
     if (ip < win.stage_block * 256u || ip + kBatchInput + ahead > win.stage_end()) {
         // Not enough staged for a batch.  Staging more pays when batches have been
         // taken lately; otherwise the one-at-a-time code stages what it needs.
@@ -583,36 +564,38 @@ __device__ __forceinline__ uint32_t take_batch(InputWindow &win, uint8_t *dst, u
     uint32_t n = 0;
     uint32_t my_ip = 0;  // lane j: sequence j
     // Only what the next token's position depends on is looked at here: the token
-    // and the literal run's extension byte.  Longer extensions make the positions
-    // from there on meaningless; the lanes find that out below and the batch ends
-    // in front of such a sequence.
+    // and the literal run's extension byte (token_lengths above).  A match length
+    // with more than one extension byte makes the positions from there on
+    // meaningless; the lanes find that out below and the batch ends in front of
+    // such a sequence.  The loop is the decoder's serial part: one v_readlane and
+    // some fifteen scalar instructions per token, four tokens per turn.  The table
+    // says 0 for positions past ip_limit, so the only tests per token are "still
+    // inside the window" and "not 0".  (The same walk in vector registers, with
+    // ds_bpermute for the table look-up, measured 4 % slower.)
     const uint32_t ip_limit = stage_end - kBatchInput;  // at least kJumpBlocks blocks are staged
-    bool doubled = false;
-    if (likely && short_tokens && ip <= ip_limit && !(tuning & 16u)) {
-        // Many sequences are expected, and the last batch's took 16 input bytes or fewer
-        // each, so that a window holds some 64 of them: all their starts at once.  (The
-        // table work grows with the window, not with the tokens in it: on longer
-        // sequences following them one by one is cheaper.)
-        uint32_t rel = 0;
-        const uint32_t room = ip_limit - ip;
-        n = find_token_starts(reinterpret_cast<const uint8_t *>(win.stage) + (ip - win.stage_block * 256u), jump,
-                              room < kWalkWindow - 1u ? room : kWalkWindow - 1u, lane, rel);
-        n = n < walk ? n : walk;
-        my_ip = lane < n ? ip + rel : 0u;
-        doubled = true;
-    } else {
-        while (ip <= ip_limit) {
-            const uint32_t r = uni(win.peek32(ip, lane));
-            const uint32_t lit = (r >> 4) & 15u;
-            uint32_t len = 3u + lit + ((r & 15u) == 15u ? 1u : 0u);
-            if (lit == 15u)
-                len += 1u + ((r >> 8) & 255u);
+    const uint32_t quota = (walk + 3u) & ~3u;           // whole turns; at most 64
+    bool more = ip <= ip_limit;
+    if (more && (win.lens_first != win.first || win.lens_limit != ip_limit))
+        win.token_lengths(ip_limit, lane);
+    while (more) {
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; ++u) {
+            uint32_t di = (ip >> 2) - win.first;
+            if (__builtin_expect(di >= 63u, 0)) {  // also catches positions before the window
+                win.slide(ip, lane);
+                win.token_lengths(ip_limit, lane);
+                di = 0;
+            }
+            const uint32_t len = (__builtin_amdgcn_readlane(win.lens, di) >> ((ip & 3u) * 8u)) & 255u;
+            if (__builtin_expect(len == 0u, 0)) {
+                more = false;  // a sequence for the one-at-a-time code starts here, or the staged input ends
+                break;
+            }
             my_ip = (lane == n) ? ip : my_ip;
             ++n;
             ip += len;
-            if (__builtin_expect(n >= walk, 0))
-                break;
         }
+        more = more && n < quota;
     }
     PHASE_MARK(clk, 0);
     if (n == 0) {
@@ -655,14 +638,8 @@ __device__ __forceinline__ uint32_t take_batch(InputWindow &win, uint8_t *dst, u
     walk = take >= walk ? (2u * walk < kWave ? 2u * walk : kWave) : (take + 4u < kWave ? take + 4u : kWave);
     if (take == 0)
         return 0;
-    // All walked sequences taken: the next token follows the last of them (its `after`
-    // is exact, the sequence having been found plain).
-    if (doubled)
-        ip = __builtin_amdgcn_readlane(after, n - 1u);
-    const uint32_t ip_before = ip_io;
     ip_io = take < n ? __builtin_amdgcn_readlane(my_ip, take) : ip;
     op_io = __builtin_amdgcn_readlane(out_end, take - 1u);
-    short_tokens = take >= 16u && ip_io - ip_before <= 16u * take;
 
     PHASE_MARK(clk, 1);
 #ifdef SNAPPY_LZ4_PHASE_SWITCHES
@@ -671,6 +648,23 @@ __device__ __forceinline__ uint32_t take_batch(InputWindow &win, uint8_t *dst, u
     const bool mine = lane < take;
     const uint32_t my_lit = mine ? lit : 0u;
     const uint32_t my_ml = mine ? ml : 0u;
+
+    // Everything a batch produces is written to the ring only and goes to memory in
+    // one piece at the end (flush_ring).  Matches whose source is older than the
+    // batch and out of the ring's reach read memory: their first loads are issued
+    // here, ahead of the literals, which touch LDS alone, so the round trip runs
+    // beside that work.  Every lane loads, from a harmless address when it has
+    // nothing to copy, so that one wait covers a step's loads.
+    const bool far = mine && !in_ring;
+    const bool any_far = !(tuning & kPhaseSwitches & 4u) && __builtin_amdgcn_ballot_w64(far) != 0;
+    const uint32_t far_len = far ? ml : 0u;
+    const uint8_t *from = dst + (far ? s : 0u);
+    uint32_t fw[kLitStep];
+    if (any_far) {
+#pragma unroll
+        for (uint32_t k = 0; k < kLitStep; ++k)
+            fw[k] = load32(from + ((4u * k < far_len) ? 4u * k : 0u));
+    }
 
     // Literals, whole dwords: up to 3 bytes too many land where the sequence's own
     // match (4 bytes at least) is written afterwards.
@@ -683,32 +677,27 @@ __device__ __forceinline__ uint32_t take_batch(InputWindow &win, uint8_t *dst, u
                     w[k] = win.staged32(lip + t + 4u * k);
 #pragma unroll
             for (uint32_t k = 0; k < kLitStep; ++k)
-                if (t + 4u * k < my_lit) {
-                    store32(dst + my_op + t + 4u * k, w[k]);
+                if (t + 4u * k < my_lit)
                     ring_write32(ring, my_op + t + 4u * k, w[k]);
-                }
         }
     }
 
     PHASE_MARK(clk, 2);
     // Matches are written to the byte: what follows a match is already in place.
-    // First those whose source is older than the batch and out of the ring's reach.
-    // Every lane loads, from a harmless address when it has nothing to copy, so
-    // that one wait covers the loads of a step and the stores behind it need none.
     bool waiting = mine;
-    if (!(tuning & kPhaseSwitches & 4u) && __builtin_amdgcn_ballot_w64(mine && !in_ring) != 0) {
-        const bool far = mine && !in_ring;
-        const uint32_t len = far ? ml : 0u;
-        const uint8_t *from = dst + (far ? s : 0u);
-        for (uint32_t t = 0; __builtin_amdgcn_ballot_w64(t < len) != 0; t += 4u * kLitStep) {
-            uint32_t w[kLitStep];
+    if (any_far) {
+        wait_for_memory();
+#pragma unroll
+        for (uint32_t k = 0; k < kLitStep; ++k)
+            put_ring(ring, mo + 4u * k, fw[k], far_len > 4u * k ? far_len - 4u * k : 0u);
+        for (uint32_t t = 4u * kLitStep; __builtin_amdgcn_ballot_w64(t < far_len) != 0; t += 4u * kLitStep) {
 #pragma unroll
             for (uint32_t k = 0; k < kLitStep; ++k)
-                w[k] = load32(from + ((t + 4u * k < len) ? t + 4u * k : 0u));
+                fw[k] = load32(from + ((t + 4u * k < far_len) ? t + 4u * k : 0u));
             wait_for_memory();
 #pragma unroll
             for (uint32_t k = 0; k < kLitStep; ++k)
-                put_exact(dst, ring, mo + t + 4u * k, w[k], len > t + 4u * k ? len - (t + 4u * k) : 0u);
+                put_ring(ring, mo + t + 4u * k, fw[k], far_len > t + 4u * k ? far_len - (t + 4u * k) : 0u);
         }
         waiting = waiting && !far;
     }
@@ -752,18 +741,20 @@ __device__ __forceinline__ uint32_t take_batch(InputWindow &win, uint8_t *dst, u
                     w[k] = ring_read32(ring, s + t + 4u * k);
 #pragma unroll
             for (uint32_t k = 0; k < kMatchStep; ++k)
-                put_exact(dst, ring, mo + t + 4u * k, w[k], len > t + 4u * k ? len - (t + 4u * k) : 0u);
+                put_ring(ring, mo + t + 4u * k, w[k], len > t + 4u * k ? len - (t + 4u * k) : 0u);
         }
         waiting = waiting && !go;
     }
     PHASE_MARK(clk, 4);
+    flush_ring(dst, ring, start, op_io, lane);
+    PHASE_MARK(clk, 3);
     return take;
 }
 
 // Decodes one compressed chunk; returns true when the block is well-formed.
 __device__ bool decode_block(const uint8_t *__restrict__ in_base, uint64_t in_alloc,
                              const Lz4Chunk &ck, uint8_t *out_base, uint8_t *ring, uint32_t *stage,
-                             uint16_t *jump, uint32_t lane, uint32_t tuning, PhaseClock &clk)
+                             uint32_t lane, uint32_t tuning, PhaseClock &clk)
 {
     const uint8_t *src = in_base + ck.in_off;
     uint8_t *dst = out_base + ck.out_off;
@@ -782,7 +773,6 @@ __device__ bool decode_block(const uint8_t *__restrict__ in_base, uint64_t in_al
     uint32_t op = 0;         // uniform
     uint32_t valid_from = 0; // uniform: the ring holds output positions [valid_from, op)
     uint32_t walk = kWave;   // uniform: tokens the next batch looks at
-    bool short_tokens = false;  // uniform: the last batch's sequences took 16 input bytes or fewer each
     uint32_t misses = 0, skip = 0;  // uniform: back-off of the batch attempts on streams of long sequences
     const uint8_t *src_al = src - in_shift;
 
@@ -795,8 +785,7 @@ __device__ bool decode_block(const uint8_t *__restrict__ in_base, uint64_t in_al
         if (skip != 0u) {
             --skip;
         } else if (!(tuning & 1u)) {
-            const uint32_t taken = take_batch(win, dst, ring, jump, ip, op, valid_from, iend, oend, walk, short_tokens, lane,
-                                              tuning, clk);
+            const uint32_t taken = take_batch(win, dst, ring, ip, op, valid_from, iend, oend, walk, lane, tuning, clk);
             if (taken >= 16u)
                 continue;  // more of the same is likely
             // Attempts that take nothing back off: 1, 3, 7, 15 sequences go by before the next one.
@@ -916,7 +905,6 @@ lz4_decode_kernel(const uint8_t *__restrict__ in_base, uint64_t in_alloc, uint8_
     __shared__ __attribute__((aligned(16))) uint8_t ring[kHist];
     const uint32_t lane = threadIdx.x & (kWave - 1);
     __shared__ uint32_t stage[kStageBlocks * 64u];
-    __shared__ uint16_t jump[2u * kWalkTable];
     // In an MCDF import the decoder runs next to a SHA-1 kernel whose waves issue an
     // instruction in nearly every slot of their SIMD.  A decoder wave spends most of its
     // time waiting for memory and LDS; when it is ready it should not queue behind that.
@@ -930,7 +918,7 @@ lz4_decode_kernel(const uint8_t *__restrict__ in_base, uint64_t in_alloc, uint8_
         if (ck.compressed) {
             PhaseClock clk;
             clk.start();
-            ok = decode_block(in_base, in_alloc, ck, out_base, ring, stage, jump, lane, tuning, clk);
+            ok = decode_block(in_base, in_alloc, ck, out_base, ring, stage, lane, tuning, clk);
             PHASE_MARK(clk, 5);
             clk.flush(lane);
         } else {
@@ -954,7 +942,7 @@ hipError_t launch_lz4_decode(const uint8_t *d_in, uint64_t in_alloc, uint8_t *d_
     // waves than the chip holds would crowd some CUs and leave others idle (1024
     // chunks: 11 % slower).  Each workgroup therefore asks for so much LDS that
     // only its share of a CU's 160 KiB fits: the waves spread evenly.
-    constexpr uint32_t kWavesPerCu = 8, kLdsPerCu = 156u << 10, kLdsUsed = kHist + kStageBlocks * 256u + 4u * kWalkTable;
+    constexpr uint32_t kWavesPerCu = 8, kLdsPerCu = 156u << 10, kLdsUsed = kHist + kStageBlocks * 256u;
     const uint32_t blocks = static_cast<uint32_t>(
         std::min<uint64_t>(n_chunks, static_cast<uint64_t>(n_cu) * kWavesPerCu));
     const uint32_t per_cu = (blocks + static_cast<uint32_t>(n_cu) - 1u) / static_cast<uint32_t>(n_cu);
