@@ -172,7 +172,7 @@ __device__ __forceinline__ HopResult hop_once(const uint8_t *__restrict__ base,
             // Phase 2: the chain hops through the group's lanes.  Groups whose
             // message has fewer blocks left than the wave's longest keep their
             // state where it is.
-            for (uint32_t s = 0; G == 64 ? s < nb : __ballot(s < nb) != 0; ++s) {
+            auto hop = [&](bool on) {
                 uint32_t a = h[0], bb = h[1], c = h[2], d = h[3], e = h[4];
 #pragma unroll
                 for (int t = 0; t < 80; ++t)
@@ -181,10 +181,25 @@ __device__ __forceinline__ HopResult hop_once(const uint8_t *__restrict__ base,
                     rotate_in_group<G>(h[0] + a), rotate_in_group<G>(h[1] + bb),
                     rotate_in_group<G>(h[2] + c), rotate_in_group<G>(h[3] + d),
                     rotate_in_group<G>(h[4] + e)};
-                const bool on = (G == 64) || s < nb;
 #pragma unroll
                 for (int k = 0; k < 5; ++k)
                     h[k] = on ? moved[k] : h[k];
+            };
+            if (G == 64) {
+                // One message for the whole wave: the count is the same in every lane, so the
+                // loop runs on a scalar counter, two blocks per turn (the jump back costs
+                // about as much as three instructions of the chain).
+                const uint32_t count = __builtin_amdgcn_readfirstlane(nb);
+                uint32_t s = 0;
+                for (; s + 2u <= count; s += 2u) {
+                    hop(true);
+                    hop(true);
+                }
+                if (s < count)
+                    hop(true);
+            } else {
+                for (uint32_t s = 0; __ballot(s < nb) != 0; ++s)
+                    hop(s < nb);
             }
         }
     }
