@@ -237,6 +237,7 @@ __device__ __forceinline__ void store_piece(uint8_t *dst, uint32_t vec, const Pi
     reinterpret_cast<uint4 *>(dst)[vec] = o;
 }
 
+template <uint32_t kDepth>
 __device__ __forceinline__ void copy_long(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src,
                                           uint32_t n, uint32_t lane)
 {
@@ -255,8 +256,9 @@ __device__ __forceinline__ void copy_long(uint8_t *__restrict__ dst, const uint8
     // Software pipeline, kDepth KiB per step: the loads of step i+1 are issued
     // before the stores of step i.  Loads and stores share one in-order counter on
     // this hardware, so a load issued behind a store cannot be waited for without
-    // waiting for the store as well; issued ahead of it, it can.
-    constexpr uint32_t kDepth = 8;
+    // waiting for the store as well; issued ahead of it, it can.  kDepth = 8 where one
+    // wave does a chunk's copies, 4 where two share them (the pieces in flight are what
+    // the kernel's register count hangs on).
     if (k + (kDepth - 1u) * kWave < n_vec) {
         Piece cur[kDepth];
 #pragma unroll
@@ -290,11 +292,12 @@ __device__ __forceinline__ void copy_long(uint8_t *__restrict__ dst, const uint8
 
 constexpr uint32_t kLongCopy = 512;
 
+template <uint32_t kDepth = 8>
 __device__ __forceinline__ void copy_run(uint8_t *dst, const uint8_t *src, uint32_t n,
                                          uint32_t lane)
 {
     if (n >= kLongCopy)
-        copy_long(dst, src, n, lane);
+        copy_long<kDepth>(dst, src, n, lane);
     else
         copy_bytes(dst, src, n, lane);
 }
@@ -305,6 +308,7 @@ __device__ __forceinline__ void copy_run(uint8_t *dst, const uint8_t *src, uint3
 // existed before the match; the rest is filled by doubling.
 constexpr uint32_t kPeriodSpan = 4096;
 
+template <uint32_t kDepth = 8>
 __device__ __forceinline__ void copy_periodic(uint8_t *dst, uint32_t period, uint32_t n,
                                               uint32_t lane)
 {
@@ -315,7 +319,7 @@ __device__ __forceinline__ void copy_periodic(uint8_t *dst, uint32_t period, uin
     if (period >= 4u * kWave) {
         // Long pattern: each repetition is a plain copy of the pattern itself.
         for (uint32_t at = 0; at < head; at += period)
-            copy_run(dst + at, pat, (head - at < period) ? head - at : period, lane);
+            copy_run<kDepth>(dst + at, pat, (head - at < period) ? head - at : period, lane);
     } else {
         uint32_t r = lane % period;
         const uint32_t step = kWave % period;
@@ -348,7 +352,7 @@ __device__ __forceinline__ void copy_periodic(uint8_t *dst, uint32_t period, uin
     // every step, and each step is one plain copy between disjoint ranges.
     for (uint32_t done = head; done < n;) {
         const uint32_t piece = (n - done < done) ? n - done : done;
-        copy_run(dst + done, dst, piece, lane);
+        copy_run<kDepth>(dst + done, dst, piece, lane);
         done += piece;
     }
 }
@@ -536,13 +540,32 @@ __device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v)
     return v;
 }
 
-// Returns the number of sequences taken.  `walk` is how many tokens the next call
-// should look at: a stream of sequences that are not for this code should not pay
-// for 64 tokens walked in vain each time.
-__device__ __forceinline__ uint32_t take_batch(InputWindow &win, uint8_t *dst, uint8_t *ring,
-                                               uint32_t &ip_io, uint32_t &op_io, uint32_t valid_from,
-                                               uint32_t iend, uint32_t oend, uint32_t &walk,
-                                               uint32_t lane, uint32_t tuning, PhaseClock &clk)
+// A batch as its first half (the walk and the classification) hands it to its
+// second (the copies): what lane j needs to know about sequence j, and the
+// figures all lanes share.
+struct BatchLane {
+    uint32_t lip;      // input position of the literals
+    uint32_t lit;      // literal bytes
+    uint32_t ml;       // match bytes
+    uint32_t off;      // match offset
+    uint32_t out_end;  // output position behind the sequence
+};
+
+struct BatchInfo {
+    uint32_t take;        // sequences in the batch: lanes 0 .. take - 1
+    uint32_t start;       // output position of the first
+    uint32_t end;         // and behind the last
+    uint32_t valid_from;  // the ring holds output positions [valid_from, start)
+};
+
+// First half.  Returns the number of sequences taken (0: none, nothing changed but
+// `walk`).  `walk` is how many tokens the next call should look at: a stream of
+// sequences that are not for this code should not pay for 64 tokens walked in vain
+// each time.
+__device__ __forceinline__ uint32_t produce_batch(InputWindow &win, uint32_t &ip_io, uint32_t &op_io,
+                                                  uint32_t valid_from, uint32_t iend, uint32_t oend,
+                                                  uint32_t &walk, uint32_t lane, PhaseClock &clk,
+                                                  BatchLane &desc, BatchInfo &info)
 {
     PHASE_MARK(clk, 5);
     uint32_t ip = ip_io;  // uniform
@@ -640,14 +663,41 @@ __device__ __forceinline__ uint32_t take_batch(InputWindow &win, uint8_t *dst, u
         return 0;
     ip_io = take < n ? __builtin_amdgcn_readlane(my_ip, take) : ip;
     op_io = __builtin_amdgcn_readlane(out_end, take - 1u);
-
+    desc.lip = lip;
+    desc.lit = lit;
+    desc.ml = ml;
+    desc.off = off;
+    desc.out_end = out_end;
+    info.take = take;
+    info.start = start;
+    info.end = op_io;
+    info.valid_from = valid_from;
     PHASE_MARK(clk, 1);
 #ifdef SNAPPY_LZ4_PHASE_SWITCHES
     clk.acc[7] += (uint64_t(1) << 32) | take;  // batches taken, sequences in them
 #endif
+    return take;
+}
+
+// Second half: the copies.  The literals come from the staged input (kFromStage:
+// the wave that walked is the one that copies) or from the chunk's input in
+// memory at src_al (another wave copies while the first walks on and may stage
+// something else).
+template <bool kFromStage>
+__device__ __forceinline__ void consume_batch(const InputWindow *win, const uint8_t *src_al, uint8_t *dst,
+                                              uint8_t *ring, const BatchLane &desc, const BatchInfo &info,
+                                              uint32_t lane, uint32_t tuning, PhaseClock &clk)
+{
+    const uint32_t take = info.take, start = info.start;
     const bool mine = lane < take;
+    const uint32_t lip = desc.lip, lit = desc.lit, ml = desc.ml, off = desc.off;
+    const uint32_t out_end = desc.out_end;
     const uint32_t my_lit = mine ? lit : 0u;
     const uint32_t my_ml = mine ? ml : 0u;
+    const uint32_t my_op = out_end - (lit + ml);
+    const uint32_t mo = my_op + lit;
+    const uint32_t s = mo - off;
+    const bool in_ring = s >= info.valid_from && s + kHist >= start + kBatchSpan;
 
     // Everything a batch produces is written to the ring only and goes to memory in
     // one piece at the end (flush_ring).  Matches whose source is older than the
@@ -668,13 +718,24 @@ __device__ __forceinline__ uint32_t take_batch(InputWindow &win, uint8_t *dst, u
 
     // Literals, whole dwords: up to 3 bytes too many land where the sequence's own
     // match (4 bytes at least) is written afterwards.
+    bool far_arrived = false;
     if (!(tuning & kPhaseSwitches & 2u)) {
         for (uint32_t t = 0; __builtin_amdgcn_ballot_w64(t < my_lit) != 0; t += 4u * kLitStep) {
             uint32_t w[kLitStep];
+            if (kFromStage) {
 #pragma unroll
-            for (uint32_t k = 0; k < kLitStep; ++k)
-                if (t + 4u * k < my_lit)
-                    w[k] = win.staged32(lip + t + 4u * k);
+                for (uint32_t k = 0; k < kLitStep; ++k)
+                    if (t + 4u * k < my_lit)
+                        w[k] = win->staged32(lip + t + 4u * k);
+            } else {
+                // From memory, every lane loading (its first literals again when it has none
+                // left), and one wait for the step, which covers the far matches' loads too.
+#pragma unroll
+                for (uint32_t k = 0; k < kLitStep; ++k)
+                    w[k] = load32(src_al + (mine ? lip : 0u) + ((t + 4u * k < my_lit) ? t + 4u * k : 0u));
+                wait_for_memory();
+                far_arrived = true;
+            }
 #pragma unroll
             for (uint32_t k = 0; k < kLitStep; ++k)
                 if (t + 4u * k < my_lit)
@@ -686,7 +747,8 @@ __device__ __forceinline__ uint32_t take_batch(InputWindow &win, uint8_t *dst, u
     // Matches are written to the byte: what follows a match is already in place.
     bool waiting = mine;
     if (any_far) {
-        wait_for_memory();
+        if (!far_arrived)
+            wait_for_memory();
 #pragma unroll
         for (uint32_t k = 0; k < kLitStep; ++k)
             put_ring(ring, mo + 4u * k, fw[k], far_len > 4u * k ? far_len - 4u * k : 0u);
@@ -746,15 +808,138 @@ __device__ __forceinline__ uint32_t take_batch(InputWindow &win, uint8_t *dst, u
         waiting = waiting && !go;
     }
     PHASE_MARK(clk, 4);
-    flush_ring(dst, ring, start, op_io, lane);
+    flush_ring(dst, ring, start, info.end, lane);
     PHASE_MARK(clk, 3);
-    return take;
+}
+
+// Who does a chunk's copies.  Solo: the wave that parses, as it goes.  Pair: a
+// second wave of the workgroup takes the batches' copies (so that they run beside
+// the walk to the next batch) and half of every long copy.  The parsing wave
+// publishes commands in LDS; the helper sits at a barrier between commands, so one
+// barrier hands a command over and, at the same time, tells the parser that the
+// command before it is finished.
+constexpr uint32_t kCmdExit = 0, kCmdSync = 1, kCmdBatch = 2, kCmdCopy = 3;
+constexpr uint32_t kTeamCopyMin = 4096;  // shorter copies are not worth two barriers
+
+struct TeamShared {
+    // Two of everything: command k uses slot k & 1, and the parser cannot get two
+    // commands ahead of the helper (every command is a barrier both must reach).
+    uint32_t cmd[2];
+    uint32_t len[2];
+    uint8_t *dst[2];
+    const uint8_t *src[2];
+    BatchInfo info[2];
+    uint32_t lanes[2][5][kWave];
+};
+
+struct SoloTeam {
+    static constexpr uint32_t kCopyDepth = 8;
+    __device__ __forceinline__ void sync() {}
+    __device__ __forceinline__ void copy(uint8_t *dst, const uint8_t *src, uint32_t n, uint32_t lane)
+    {
+        copy_run(dst, src, n, lane);
+    }
+    __device__ __forceinline__ void batch(const InputWindow &win, const uint8_t *, uint8_t *dst, uint8_t *ring,
+                                          const BatchLane &desc, const BatchInfo &info, uint32_t lane,
+                                          uint32_t tuning, PhaseClock &clk)
+    {
+        consume_batch<true>(&win, nullptr, dst, ring, desc, info, lane, tuning, clk);
+    }
+};
+
+struct PairTeam {
+    static constexpr uint32_t kCopyDepth = 4;
+    TeamShared *sh;
+    uint32_t seq;   // commands published so far
+    bool pending;   // the helper may still be busy with a batch
+
+    // Every lane stores the same words.  The parser's own stores to memory are
+    // complete before the helper may read what they wrote.
+    __device__ __forceinline__ void publish(uint32_t cmd, uint8_t *dst, const uint8_t *src, uint32_t n)
+    {
+        const uint32_t slot = seq & 1u;
+        sh->cmd[slot] = cmd;
+        sh->len[slot] = n;
+        sh->dst[slot] = dst;
+        sh->src[slot] = src;
+        wait_for_memory();
+        __syncthreads();
+        ++seq;
+        pending = cmd == kCmdBatch;
+    }
+    __device__ __forceinline__ void sync()
+    {
+        if (pending)
+            publish(kCmdSync, nullptr, nullptr, 0);
+    }
+    __device__ __forceinline__ void copy(uint8_t *dst, const uint8_t *src, uint32_t n, uint32_t lane)
+    {
+        if (n < kTeamCopyMin) {
+            sync();
+            copy_run<kCopyDepth>(dst, src, n, lane);
+            return;
+        }
+        publish(kCmdCopy, dst, src, n);  // the helper takes [half, n)
+        const uint32_t half = (n >> 1) & ~15u;
+        copy_run<kCopyDepth>(dst, src, half, lane);
+        wait_for_memory();
+        __syncthreads();
+    }
+    __device__ __forceinline__ void batch(const InputWindow &, const uint8_t *src_al, uint8_t *dst, uint8_t *,
+                                          const BatchLane &desc, const BatchInfo &info, uint32_t lane, uint32_t,
+                                          PhaseClock &)
+    {
+        const uint32_t slot = seq & 1u;
+        sh->lanes[slot][0][lane] = desc.lip;
+        sh->lanes[slot][1][lane] = desc.lit;
+        sh->lanes[slot][2][lane] = desc.ml;
+        sh->lanes[slot][3][lane] = desc.off;
+        sh->lanes[slot][4][lane] = desc.out_end;
+        sh->info[slot] = info;
+        publish(kCmdBatch, dst, src_al, 0);
+    }
+};
+
+// The helper wave of a pair: carries out the parser's commands until told to leave.
+__device__ void helper_loop(TeamShared *sh, uint8_t *ring, uint32_t lane, uint32_t tuning)
+{
+    PhaseClock clk;
+    clk.start();
+    for (uint32_t seq = 0;; ++seq) {
+        __syncthreads();
+        const uint32_t slot = seq & 1u;
+        const uint32_t cmd = uni(sh->cmd[slot]);
+        if (cmd == kCmdExit)
+            return;
+        if (cmd == kCmdBatch) {
+            BatchLane desc;
+            desc.lip = sh->lanes[slot][0][lane];
+            desc.lit = sh->lanes[slot][1][lane];
+            desc.ml = sh->lanes[slot][2][lane];
+            desc.off = sh->lanes[slot][3][lane];
+            desc.out_end = sh->lanes[slot][4][lane];
+            BatchInfo info;
+            info.take = uni(sh->info[slot].take);
+            info.start = uni(sh->info[slot].start);
+            info.end = uni(sh->info[slot].end);
+            info.valid_from = uni(sh->info[slot].valid_from);
+            consume_batch<false>(nullptr, sh->src[slot], sh->dst[slot], ring, desc, info, lane, tuning, clk);
+            wait_for_memory();  // the flush is in memory before the parser is told so
+        } else if (cmd == kCmdCopy) {
+            const uint32_t n = uni(sh->len[slot]);
+            const uint32_t half = (n >> 1) & ~15u;
+            copy_run<PairTeam::kCopyDepth>(sh->dst[slot] + half, sh->src[slot] + half, n - half, lane);
+            wait_for_memory();
+            __syncthreads();
+        }
+    }
 }
 
 // Decodes one compressed chunk; returns true when the block is well-formed.
-__device__ bool decode_block(const uint8_t *__restrict__ in_base, uint64_t in_alloc,
-                             const Lz4Chunk &ck, uint8_t *out_base, uint8_t *ring, uint32_t *stage,
-                             uint32_t lane, uint32_t tuning, PhaseClock &clk)
+template <typename Team>
+__device__ bool decode_sequences(const uint8_t *__restrict__ in_base, uint64_t in_alloc,
+                                 const Lz4Chunk &ck, uint8_t *out_base, uint8_t *ring, uint32_t *stage,
+                                 uint32_t lane, uint32_t tuning, PhaseClock &clk, Team &team)
 {
     const uint8_t *src = in_base + ck.in_off;
     uint8_t *dst = out_base + ck.out_off;
@@ -785,13 +970,19 @@ __device__ bool decode_block(const uint8_t *__restrict__ in_base, uint64_t in_al
         if (skip != 0u) {
             --skip;
         } else if (!(tuning & 1u)) {
-            const uint32_t taken = take_batch(win, dst, ring, ip, op, valid_from, iend, oend, walk, lane, tuning, clk);
+            BatchLane desc;
+            BatchInfo info;
+            const uint32_t taken = produce_batch(win, ip, op, valid_from, iend, oend, walk, lane, clk, desc, info);
+            if (taken != 0u)
+                team.batch(win, src_al, dst, ring, desc, info, lane, tuning, clk);
             if (taken >= 16u)
                 continue;  // more of the same is likely
             // Attempts that take nothing back off: 1, 3, 7, 15 sequences go by before the next one.
             misses = taken != 0u ? 0u : (2u * misses + 1u < 15u ? 2u * misses + 1u : 15u);
             skip = misses;
         }
+        // What follows writes the ring and memory itself: the batches before it are finished first.
+        team.sync();
         if (ip >= iend)
             return false;
         uint32_t bytes = uni(win.peek32(ip, lane));
@@ -832,7 +1023,7 @@ __device__ bool decode_block(const uint8_t *__restrict__ in_base, uint64_t in_al
             win.cover(ip, lit, lane);
             emit_short_literals(win, ip, lit, dst, ring, op, lane);
         } else if (lit != 0u) {
-            copy_run(dst + op, src_al + ip, lit, lane);
+            team.copy(dst + op, src_al + ip, lit, lane);
             valid_from = op + lit;
         }
         ip += lit;
@@ -887,14 +1078,25 @@ __device__ bool decode_block(const uint8_t *__restrict__ in_base, uint64_t in_al
             uint8_t *mdst = dst + op;
             const uint8_t *msrc = mdst - offset;
             if (offset >= ml) {
-                copy_run(mdst, msrc, ml, lane);
+                team.copy(mdst, msrc, ml, lane);
             } else {
-                copy_periodic(mdst, offset, ml, lane);
+                copy_periodic<Team::kCopyDepth>(mdst, offset, ml, lane);
             }
             valid_from = op + ml;
         }
         op += ml;
     }
+}
+
+// The same, and every copy handed out on the way is finished when it returns.
+template <typename Team>
+__device__ bool decode_block(const uint8_t *__restrict__ in_base, uint64_t in_alloc, const Lz4Chunk &ck,
+                             uint8_t *out_base, uint8_t *ring, uint32_t *stage, uint32_t lane, uint32_t tuning,
+                             PhaseClock &clk, Team &team)
+{
+    const bool ok = decode_sequences(in_base, in_alloc, ck, out_base, ring, stage, lane, tuning, clk, team);
+    team.sync();
+    return ok;
 }
 
 __global__ void __launch_bounds__(kWave)
@@ -909,6 +1111,7 @@ lz4_decode_kernel(const uint8_t *__restrict__ in_base, uint64_t in_alloc, uint8_
     // instruction in nearly every slot of their SIMD.  A decoder wave spends most of its
     // time waiting for memory and LDS; when it is ready it should not queue behind that.
     __builtin_amdgcn_s_setprio(3);
+    SoloTeam team;
     for (;;) {
         const uint32_t i = wave_claim(queue, 1u, lane);
         if (i >= n_chunks)
@@ -918,7 +1121,7 @@ lz4_decode_kernel(const uint8_t *__restrict__ in_base, uint64_t in_alloc, uint8_
         if (ck.compressed) {
             PhaseClock clk;
             clk.start();
-            ok = decode_block(in_base, in_alloc, ck, out_base, ring, stage, lane, tuning, clk);
+            ok = decode_block(in_base, in_alloc, ck, out_base, ring, stage, lane, tuning, clk, team);
             PHASE_MARK(clk, 5);
             clk.flush(lane);
         } else {
@@ -927,6 +1130,44 @@ lz4_decode_kernel(const uint8_t *__restrict__ in_base, uint64_t in_alloc, uint8_
         // Every lane stores the same word: no lane-0-only tail (see wave_claim).
         status[i] = ok ? 0u : 1u;
     }
+}
+
+// Two waves per chunk: wave 0 parses, wave 1 copies (PairTeam above).  Both leave
+// through one door: the helper returns on the parser's last command, which the
+// parser sends when the queue is empty, whatever happened to its chunks.
+__global__ void __launch_bounds__(2 * kWave)
+lz4_decode_pair_kernel(const uint8_t *__restrict__ in_base, uint64_t in_alloc, uint8_t *out_base,
+                       const Lz4Chunk *__restrict__ chunks, uint32_t n_chunks,
+                       uint32_t *__restrict__ queue, uint32_t *__restrict__ status, uint32_t tuning)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t ring[kHist];
+    __shared__ uint32_t stage[kStageBlocks * 64u];
+    __shared__ TeamShared shared;
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    __builtin_amdgcn_s_setprio(3);
+    if (threadIdx.x >= kWave) {
+        helper_loop(&shared, ring, lane, tuning);
+        return;
+    }
+    PairTeam team{&shared, 0u, false};
+    for (;;) {
+        const uint32_t i = wave_claim(queue, 1u, lane);
+        if (i >= n_chunks)
+            break;
+        const Lz4Chunk ck = chunks[i];
+        bool ok = true;
+        if (ck.compressed) {
+            PhaseClock clk;
+            clk.start();
+            ok = decode_block(in_base, in_alloc, ck, out_base, ring, stage, lane, tuning, clk, team);
+            PHASE_MARK(clk, 5);
+            clk.flush(lane);
+        } else {
+            team.copy(out_base + ck.out_off, in_base + ck.in_off, ck.orig_len, lane);
+        }
+        status[i] = ok ? 0u : 1u;
+    }
+    team.publish(kCmdExit, nullptr, nullptr, 0);
 }
 
 }  // namespace
@@ -956,7 +1197,8 @@ hipError_t launch_lz4_decode(const uint8_t *d_in, uint64_t in_alloc, uint8_t *d_
         (void)hipGetLastError();
         pad_lds = (64u << 10) - kLdsUsed;
     }
-    // SNAPPY_LZ4_TUNING, bit 0: every sequence takes the one-at-a-time path (for comparisons).
+    // SNAPPY_LZ4_TUNING, bit 0: every sequence takes the one-at-a-time path (for comparisons);
+    // bit 5 (32): one wave per chunk instead of two.
     static const uint32_t tuning = [] {
         const char *env = std::getenv("SNAPPY_LZ4_TUNING");
         return env ? static_cast<uint32_t>(std::strtoul(env, nullptr, 0)) : 0u;
@@ -965,8 +1207,21 @@ hipError_t launch_lz4_decode(const uint8_t *d_in, uint64_t in_alloc, uint8_t *d_
     unsigned long long zero[8] = {};
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), zero, sizeof zero);
 #endif
-    hipLaunchKernelGGL(lz4_decode_kernel, dim3(blocks), dim3(kWave), pad_lds, stream, d_in, in_alloc, d_out,
-                       d_chunks, n_chunks, d_queue, d_status, tuning);
+    if (!(tuning & 32u)) {
+        constexpr uint32_t kPairLds = kLdsUsed + static_cast<uint32_t>(sizeof(TeamShared));
+        uint32_t pad = share > kPairLds ? share - kPairLds : 0u;
+        if (kPairLds + pad > (64u << 10) &&
+            hipFuncSetAttribute(reinterpret_cast<const void *>(lz4_decode_pair_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 96 << 10) != hipSuccess) {
+            (void)hipGetLastError();
+            pad = (64u << 10) - kPairLds;
+        }
+        hipLaunchKernelGGL(lz4_decode_pair_kernel, dim3(blocks), dim3(2 * kWave), pad, stream, d_in, in_alloc, d_out,
+                           d_chunks, n_chunks, d_queue, d_status, tuning);
+    } else {
+        hipLaunchKernelGGL(lz4_decode_kernel, dim3(blocks), dim3(kWave), pad_lds, stream, d_in, in_alloc, d_out,
+                           d_chunks, n_chunks, d_queue, d_status, tuning);
+    }
 #ifdef SNAPPY_LZ4_PHASE_SWITCHES
     (void)hipStreamSynchronize(stream);
     unsigned long long c[8];

@@ -295,15 +295,17 @@ def test_dense_short_sequences_corrupted(snappy, oracle):
             assert got == want, pos
 
 
-def test_one_sequence_at_a_time_path():
-    """The same block and stream tests with the batch path switched off (the switch is read once per
-    process, hence the child): both ways through the decoder stay covered."""
+@pytest.mark.parametrize("tuning", ["1", "32", "33"])
+def test_other_ways_through_the_decoder(tuning):
+    """The same block and stream tests with the batch path switched off (bit 0), with one wave per
+    chunk instead of two (bit 5), and with both (the switches are read once per process, hence the
+    child): every way through the decoder stays covered."""
     import os
     import subprocess
     import sys
     if os.environ.get("SNAPPY_LZ4_TUNING"):
         pytest.skip("already the child")
-    env = dict(os.environ, SNAPPY_LZ4_TUNING="1")
+    env = dict(os.environ, SNAPPY_LZ4_TUNING=tuning)
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-p", "no:cacheprovider", __file__, "-k",
                         "dense or vectors or golden or framing or generated or corruptions"],
                        env=env, capture_output=True, text=True, timeout=600)

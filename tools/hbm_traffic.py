@@ -14,8 +14,8 @@ PASSES = {  # summary section -> (workload key, kernel)
     "corpus": ("corpus", "sha1_hop_kernel"),
     "blobs": ("blobs", "sha1_hop_kernel"),
     "small": ("small", "sha1_hop_kernel"),
-    "mcdf": ("mcdf", "lz4_decode_kernel"),
-    "dense": ("mcdf_dense", "lz4_decode_kernel"),
+    "mcdf": ("mcdf", "lz4_decode_pair_kernel"),
+    "dense": ("mcdf_dense", "lz4_decode_pair_kernel"),
 }
 
 
