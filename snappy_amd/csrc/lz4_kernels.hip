@@ -469,13 +469,13 @@ constexpr uint32_t kBatchLit = 240;
 // (tuning bits 1-3; the output is then wrong) to see what each costs.
 #ifdef SNAPPY_LZ4_PHASE_SWITCHES
 constexpr uint32_t kPhaseSwitches = 0xEu;
-__device__ unsigned long long g_phase_cycles[8];
+__device__ unsigned long long g_phase_cycles[9];
 struct PhaseClock {
     uint64_t last;
-    uint64_t acc[8];
-    __device__ void start() { last = __builtin_amdgcn_s_memtime(); for (int i = 0; i < 8; ++i) acc[i] = 0; }
+    uint64_t acc[9];
+    __device__ void start() { last = __builtin_amdgcn_s_memtime(); for (int i = 0; i < 9; ++i) acc[i] = 0; }
     __device__ void mark(int phase) { const uint64_t now = __builtin_amdgcn_s_memtime(); acc[phase] += now - last; last = now; }
-    __device__ void flush(uint32_t lane) { if (lane == 0) for (int i = 0; i < 8; ++i) atomicAdd(&g_phase_cycles[i], acc[i]); }
+    __device__ void flush(uint32_t lane) { if (lane == 0) for (int i = 0; i < 9; ++i) atomicAdd(&g_phase_cycles[i], acc[i]); }
 };
 #define PHASE_MARK(clock, phase) (clock).mark(phase)
 #else
@@ -909,8 +909,11 @@ __device__ void helper_loop(TeamShared *sh, uint8_t *ring, uint32_t lane, uint32
         __syncthreads();
         const uint32_t slot = seq & 1u;
         const uint32_t cmd = uni(sh->cmd[slot]);
-        if (cmd == kCmdExit)
+        PHASE_MARK(clk, 8);  // measurement builds: the helper's time at the barrier
+        if (cmd == kCmdExit) {
+            clk.flush(lane);
             return;
+        }
         if (cmd == kCmdBatch) {
             BatchLane desc;
             desc.lip = sh->lanes[slot][0][lane];
@@ -1204,7 +1207,7 @@ hipError_t launch_lz4_decode(const uint8_t *d_in, uint64_t in_alloc, uint8_t *d_
         return env ? static_cast<uint32_t>(std::strtoul(env, nullptr, 0)) : 0u;
     }();
 #ifdef SNAPPY_LZ4_PHASE_SWITCHES
-    unsigned long long zero[8] = {};
+    unsigned long long zero[9] = {};
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), zero, sizeof zero);
 #endif
     if (!(tuning & 32u)) {
@@ -1224,10 +1227,10 @@ hipError_t launch_lz4_decode(const uint8_t *d_in, uint64_t in_alloc, uint8_t *d_
     }
 #ifdef SNAPPY_LZ4_PHASE_SWITCHES
     (void)hipStreamSynchronize(stream);
-    unsigned long long c[8];
+    unsigned long long c[9];
     (void)hipMemcpyFromSymbol(c, HIP_SYMBOL(g_phase_cycles), sizeof c);
     fprintf(stderr, "lz4 phases (s_memtime ticks summed over %u chunks): walk %llu classify %llu literals %llu "
-                    "old sources %llu rounds %llu one-at-a-time %llu staging %llu; %llu batches of %.1f sequences\n", n_chunks, c[0], c[1], c[2], c[3], c[4], c[5], c[6],
+                    "old sources %llu rounds %llu one-at-a-time %llu staging %llu helper waiting %llu; %llu batches of %.1f sequences\n", n_chunks, c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[8],
             c[7] >> 32, static_cast<double>(c[7] & 0xFFFFFFFFull) / static_cast<double>((c[7] >> 32) ? (c[7] >> 32) : 1));
 #endif
     return hipGetLastError();
