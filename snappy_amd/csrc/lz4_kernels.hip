@@ -493,14 +493,22 @@ constexpr uint32_t kLitStep = 8;        // dwords a lane has in flight per step 
 constexpr uint32_t kMatchStep = 4;      // and matches: a match may repeat a pattern of 16 bytes or more
 
 // The first `count` (at most 4 count) bytes of `w` go to output position `pos` of
-// the ring: a batch's output goes to memory in one piece at its end.
+// the ring: a batch's output goes to memory in one piece at its end.  A match's
+// last, partial dword is merged into the four bytes that are there and written
+// back whole (one read, one write, instead of a loop over bytes that the whole
+// wave walks through whenever one lane has such a tail, which is always).  The
+// bytes behind the match that are written back unchanged belong to the next
+// sequence: its literals, which are final by now, or the first dword of its match,
+// which that lane writes whole, before this read or after this write (the two
+// kinds of store are different instructions of the same wave).
 __device__ __forceinline__ void put_ring(uint8_t *ring, uint32_t pos, uint32_t w, uint32_t count)
 {
     if (count >= 4u) {
         ring_write32(ring, pos, w);
-    } else {
-        for (uint32_t q = 0; q < count; ++q)
-            ring[(pos + q) & (kHist - 1u)] = static_cast<uint8_t>(w >> (8u * q));
+    } else if (count != 0u) {
+        const uint32_t mine = 0xFFFFFFFFu >> (8u * (4u - count));
+        const uint32_t old = ring_read32(ring, pos);
+        ring_write32(ring, pos, (w & mine) | (old & ~mine));
     }
 }
 
