@@ -308,8 +308,8 @@ __device__ __forceinline__ void copy_run(uint8_t *dst, const uint8_t *src, uint3
 // existed before the match; the rest is filled by doubling.
 constexpr uint32_t kPeriodSpan = 4096;
 
-template <uint32_t kDepth = 8>
-__device__ __forceinline__ void copy_periodic(uint8_t *dst, uint32_t period, uint32_t n,
+template <typename Team>
+__device__ __forceinline__ void copy_periodic(Team &team, uint8_t *dst, uint32_t period, uint32_t n,
                                               uint32_t lane)
 {
     const uint8_t *pat = dst - period;
@@ -319,7 +319,7 @@ __device__ __forceinline__ void copy_periodic(uint8_t *dst, uint32_t period, uin
     if (period >= 4u * kWave) {
         // Long pattern: each repetition is a plain copy of the pattern itself.
         for (uint32_t at = 0; at < head; at += period)
-            copy_run<kDepth>(dst + at, pat, (head - at < period) ? head - at : period, lane);
+            team.copy(dst + at, pat, (head - at < period) ? head - at : period, lane);
     } else {
         uint32_t r = lane % period;
         const uint32_t step = kWave % period;
@@ -352,7 +352,7 @@ __device__ __forceinline__ void copy_periodic(uint8_t *dst, uint32_t period, uin
     // every step, and each step is one plain copy between disjoint ranges.
     for (uint32_t done = head; done < n;) {
         const uint32_t piece = (n - done < done) ? n - done : done;
-        copy_run<kDepth>(dst + done, dst, piece, lane);
+        team.copy(dst + done, dst, piece, lane);
         done += piece;
     }
 }
@@ -841,7 +841,6 @@ struct TeamShared {
 };
 
 struct SoloTeam {
-    static constexpr uint32_t kCopyDepth = 8;
     __device__ __forceinline__ void sync() {}
     __device__ __forceinline__ void copy(uint8_t *dst, const uint8_t *src, uint32_t n, uint32_t lane)
     {
@@ -1091,7 +1090,7 @@ __device__ bool decode_sequences(const uint8_t *__restrict__ in_base, uint64_t i
             if (offset >= ml) {
                 team.copy(mdst, msrc, ml, lane);
             } else {
-                copy_periodic<Team::kCopyDepth>(mdst, offset, ml, lane);
+                copy_periodic(team, mdst, offset, ml, lane);
             }
             valid_from = op + ml;
         }
