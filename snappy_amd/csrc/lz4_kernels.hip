@@ -609,6 +609,10 @@ __device__ __forceinline__ uint32_t produce_batch(InputWindow &win, uint32_t &ip
     if (more && (win.lens_first != win.first || win.lens_limit != ip_limit))
         win.token_lengths(ip_limit, lane);
     while (more) {
+        // A length of 0 (a sequence for the one-at-a-time code starts here, or the staged
+        // input ends) stops the walk where it is: the steps left in the turn find the
+        // same 0 at the same place and change nothing, so one test per turn will do.
+        uint32_t len = 0;
 #pragma unroll
         for (uint32_t u = 0; u < 4u; ++u) {
             uint32_t di = (ip >> 2) - win.first;
@@ -617,16 +621,12 @@ __device__ __forceinline__ uint32_t produce_batch(InputWindow &win, uint32_t &ip
                 win.token_lengths(ip_limit, lane);
                 di = 0;
             }
-            const uint32_t len = (__builtin_amdgcn_readlane(win.lens, di) >> ((ip & 3u) * 8u)) & 255u;
-            if (__builtin_expect(len == 0u, 0)) {
-                more = false;  // a sequence for the one-at-a-time code starts here, or the staged input ends
-                break;
-            }
+            len = (__builtin_amdgcn_readlane(win.lens, di) >> ((ip & 3u) * 8u)) & 255u;
             my_ip = (lane == n) ? ip : my_ip;
-            ++n;
+            n += len != 0u ? 1u : 0u;
             ip += len;
         }
-        more = more && n < quota;
+        more = len != 0u && n < quota;
     }
     PHASE_MARK(clk, 0);
     if (n == 0) {
