@@ -246,7 +246,7 @@ def test_plan_shards_lpt_properties(snappy):
 
 
 def test_integration_text_matches_the_library(snappy):
-    """The P/Invoke declarations a maintainer would paste against the header and the
+    """The P/Invoke declarations a maintainer would paste (the integration notes at the repository root) against the header and the
     ctypes table: same names, same number of arguments, pointers where the C side has pointers,
     integers of the same width."""
     text = open(os.path.join(H.ROOT, "INTEGRATION.md")).read()

@@ -2,7 +2,7 @@
 """Turns the counter rows of a tools/collect_profiles.sh summary into HBM bytes per launch of the
 dominant kernel of each workload, beside the algorithmic bytes the bench line states.
 
-  python tools/hbm_traffic.py gpurun_out/r02/summary.txt gpurun_out/bench_r02.json > profiles/hbm_traffic.json
+  python tools/hbm_traffic.py gpurun_out/<tag>/summary.txt <bench line>.json > profiles/hbm_traffic.json
 
 FETCH_SIZE and WRITE_SIZE are reported in KiB; gfx950 tallies a 128-byte read request as 64
 bytes, so reads are doubled (writes are not)."""
