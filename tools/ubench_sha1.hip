@@ -12,6 +12,7 @@
 //   mode 6: the loads of mode 4 regrouped so that the four lanes of a quad read the 64 bytes
 //           of one message's block together (the words land in the wrong lanes: this measures
 //           the loads only, not a usable hash)
+//   mode 14: mode 4's data through LDS-DMA (global_load_lds_dwordx4 into LDS, read back per lane), double-buffered
 //   modes 12, 13: mode 4 with four or two blocks (256 or 128 contiguous bytes) loaded per lane at a time
 //   mode 11: mode 6 with non-temporal loads (no L1 allocation)
 //   mode 10: mode 4 with each block's first load issued two blocks ahead of its other three
@@ -107,6 +108,40 @@ bench(const uint8_t *base, uint64_t stride, uint32_t blocks_per_lane, uint32_t *
             for (int t = 0; t < 80; ++t)
                 sha1_round<true>(t, a, bb, c, dd, e, wk[t * 64 + lane]);
             h[0] += a; h[1] += bb; h[2] += c; h[3] += dd; h[4] += e;
+        }
+    } else if (MODE == 14) {
+        // LDS-DMA: every lane's next block goes from memory straight into LDS
+        // (global_load_lds_dwordx4: no vector registers on the way, lane l's 16 bytes land at
+        // base + 16 l), two buffers in turn, and is read back by its lane with four ds_read_b128.
+        __shared__ __attribute__((aligned(16))) uint8_t dma[4][2][4][64 * 16];  // wave, buffer, piece, lane
+        uint8_t *mine = &dma[wave][0][0][0];
+        auto fetch = [&](uint32_t b, uint32_t buf) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint32_t *>(p + uint64_t(b) * 64 + q * 16),
+                                                 reinterpret_cast<uint32_t *>(mine + (buf * 4 + q) * 1024), 16, 0, 0);
+        };
+        fetch(0, 0);
+        for (uint32_t b = 0; b < blocks_per_lane; ++b) {
+            const uint32_t buf = b & 1u;
+            if (b + 1 < blocks_per_lane)
+                fetch(b + 1, buf ^ 1u);
+            // the four loads of block b were issued before the (up to) four of block b + 1
+            if (b + 1 < blocks_per_lane)
+                __builtin_amdgcn_s_waitcnt(0x0F74);  // vmcnt(4)
+            else
+                __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const volatile uint4 *src = reinterpret_cast<const volatile uint4 *>(mine + (buf * 4 + q) * 1024 + lane * 16);
+                const uint32_t x = src->x, y = src->y, z = src->z, ww = src->w;
+                w[4 * q] = __builtin_amdgcn_perm(x, x, 0x00010203u);
+                w[4 * q + 1] = __builtin_amdgcn_perm(y, y, 0x00010203u);
+                w[4 * q + 2] = __builtin_amdgcn_perm(z, z, 0x00010203u);
+                w[4 * q + 3] = __builtin_amdgcn_perm(ww, ww, 0x00010203u);
+            }
+            sha1_compress(h, w);
         }
     } else if (MODE == 12 || MODE == 13) {
         // Mode 4 with 256 (mode 12) or 128 (mode 13) contiguous bytes asked for per lane and visit:
@@ -215,6 +250,13 @@ bench(const uint8_t *base, uint64_t stride, uint32_t blocks_per_lane, uint32_t *
     }
 }
 
+// Data that differs from place to place, so that a mode that delivers the wrong bytes shows in the check word.
+__global__ void fill(uint32_t *d, size_t n)
+{
+    for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x)
+        d[i] = uint32_t(i) * 2654435761u ^ uint32_t(i >> 7);
+}
+
 template <int MODE>
 static void run(int blocks_per_cu, uint32_t blocks_per_lane, const uint8_t *d_data, uint64_t stride)
 {
@@ -234,15 +276,17 @@ static void run(int blocks_per_cu, uint32_t blocks_per_lane, const uint8_t *d_da
     (void)hipEventSynchronize(e1);
     float ms = 0;
     (void)hipEventElapsedTime(&ms, e0, e1);
+    uint32_t first_sink = 0;
+    (void)hipMemcpy(&first_sink, d_sink + 77, 4, hipMemcpyDeviceToHost);
     uint64_t clks[2] = {0, 0};
     (void)hipMemcpy(clks, d_clk, 16, hipMemcpyDeviceToHost);
     const uint64_t clk = clks[0];
     const double bytes = double(grid) * threads * blocks_per_lane * 64.0;
     const double waves = double(grid) * 4;
-    printf("mode %d  waves/SIMD=%d  blocks/lane=%u  %.3f ms  %.1f GB/s  %.2f ns/block/wave  memtime ticks=%llu (%.3f GHz if ticks are cycles)  wave 0: %llu memtime ticks in %llu ticks of 10 ns = %.3f ticks/ns\n",
+    printf("mode %d  waves/SIMD=%d  blocks/lane=%u  %.3f ms  %.1f GB/s  %.2f ns/block/wave  memtime ticks=%llu (%.3f GHz if ticks are cycles)  wave 0: %llu memtime ticks in %llu ticks of 10 ns = %.3f ticks/ns  check %08x\n",
            MODE, blocks_per_cu, blocks_per_lane, ms, bytes / ms / 1e6, ms * 1e6 / blocks_per_lane, (unsigned long long)clk,
            double(clk) / (ms * 1e6), (unsigned long long)clks[0], (unsigned long long)clks[1],
-           clks[1] ? double(clks[0]) / (10.0 * double(clks[1])) : 0.0);
+           clks[1] ? double(clks[0]) / (10.0 * double(clks[1])) : 0.0, first_sink);
     (void)waves;
     (void)hipFree(d_sink);
     (void)hipFree(d_clk);
@@ -262,7 +306,8 @@ int main(int argc, char **argv)
     uint8_t *d_data;
     const size_t bytes = size_t(256) * 8 * 256 * stride + 4096;
     (void)hipMalloc(&d_data, bytes);
-    (void)hipMemset(d_data, 0x5A, bytes);
+    hipLaunchKernelGGL(fill, dim3(4096), dim3(256), 0, 0, reinterpret_cast<uint32_t *>(d_data), bytes / 4);
+    (void)hipDeviceSynchronize();
     for (int w : {1, 2, 4, 8})
         run<0>(w, 2048, d_data, stride);
     run<7>(1, 2048, d_data, stride);
@@ -274,6 +319,8 @@ int main(int argc, char **argv)
         run<4>(w, bpl, d_data, stride);
     for (int w : {1, 2, 4, 8})
         run<10>(w, bpl, d_data, stride);
+    for (int w : {1, 2, 4})
+        run<14>(w, bpl, d_data, stride);
     for (int w : {1, 2, 4})
         run<13>(w, bpl, d_data, stride);
     for (int w : {1, 2, 4})
