@@ -342,10 +342,35 @@ def run_mcdf(args, rank, world, local_rank, dist):
                      # Inside the import the decode is split per archive and runs next to the waiting
                      # SHA-1 kernel, behind each archive's transfer; these are those launches' times added up.
                      "import_decode_launches_ms": float(np.mean(lz4_ms)),
-                     "sha1_kernel_ms": float(np.mean(sha_ms))},
+                     "sha1_kernel_ms": float(np.mean(sha_ms)),
+                     # What a plain device-to-device copy of the decoded size moves on this box (read + write):
+                     # the practical ceiling next to the 8 TB/s of the data sheet.
+                     "device_copy_GBps_measured": device_copy_rate(torch, min(out_bytes, 2 << 30))},
         "digests_match_hashlib_sample": bool(ok),
         **({"cpu_baseline": cpu} if cpu else {}),
     }
+
+
+def device_copy_rate(torch, n):
+    """GB/s (read + write) of a device-to-device copy of n bytes: what the memory system gives a kernel
+    that does nothing but stream."""
+    try:
+        x = torch.empty(n, dtype=torch.uint8, device="cuda")
+        y = torch.empty_like(x)
+        for _ in range(2):
+            y.copy_(x)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            y.copy_(x)
+        e1.record()
+        torch.cuda.synchronize()
+        rate = 2.0 * n * 5 / (e0.elapsed_time(e1) * 1e-3) / GB
+        del x, y
+        return rate
+    except Exception:   # out of memory next to the workload: the figure is an extra, not the result
+        return None
 
 
 def decode_in_one_launch(lib, native, streams, sizes, first_payload):
