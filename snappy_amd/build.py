@@ -13,7 +13,11 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-LIB = os.path.join(HERE, "libsnappyhash.so")
+# SNAPPY_BUILD_TAG=<tag> builds a variant beside the product (objects in _obj_<tag>, library
+# libsnappyhash_<tag>.so), e.g. a measurement build with SNAPPY_EXTRA_CXXFLAGS; tools load it
+# through SNAPPY_LIB_PATH.
+TAG = os.environ.get("SNAPPY_BUILD_TAG", "")
+LIB = os.path.join(HERE, f"libsnappyhash_{TAG}.so" if TAG else "libsnappyhash.so")
 
 SOURCES = [
     "sha1_kernels.hip",
@@ -47,7 +51,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
     headers.append(os.path.join(HERE, "..", "include", "snappyhash.h"))
-    objdir = os.path.join(HERE, "_obj")
+    objdir = os.path.join(HERE, f"_obj_{TAG}" if TAG else "_obj")
     os.makedirs(objdir, exist_ok=True)
     hipcc = _hipcc()
     common = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wextra",

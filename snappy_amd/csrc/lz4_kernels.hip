@@ -37,6 +37,8 @@ namespace {
 constexpr int kWave = 64;
 constexpr uint32_t kCopyLength = 8;
 
+typedef __attribute__((address_space(3))) uint8_t LdsByte;  // an LDS address is 32 bits
+
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 
 // All vector memory operations issued so far have completed (s_waitcnt vmcnt(0);
@@ -62,9 +64,6 @@ struct InputWindow {
     uint32_t stage_count;     // uniform: blocks staged
     uint32_t first;           // uniform: number of the dword held by lane 0
     uint32_t a;               // per lane: dword first + lane
-    uint32_t lens;            // per lane: see token_lengths(); belongs to the window at lens_first
-    uint32_t lens_first;      // uniform
-    uint32_t lens_limit;      // uniform: the limit the table was made for
 
     // Every wait is placed here, on the paths that move the window.  A wait left
     // to the compiler lands where the paths join again, is executed by every
@@ -124,39 +123,6 @@ struct InputWindow {
     {
         restage(0, false, lane);
         slide(0, lane);
-        lens_first = 0xFFFFFFFFu;
-    }
-
-    // For each of the lane's four byte positions: how far the next token is if a
-    // token starts there and its sequence is one the batches take (a literal run
-    // with at most one length-extension byte, a match with at most one), one
-    // byte per position; 0 where that cannot be said (a longer extension, or a
-    // distance that does not fit a byte) and for positions past `limit`, the last
-    // one a batch's sequence may start at.  It takes the token and the byte behind
-    // it, nothing else, so all 256 positions of the window are done side by side
-    // and the serial walk from token to token is left with one v_readlane and a
-    // few scalar operations per token.  Lane 63's last position looks at a byte
-    // outside the window; the walk moves the window before it gets there.
-    __device__ __forceinline__ void token_lengths(uint32_t limit, uint32_t lane)
-    {
-        // The dword of the lane above (wave_shl:1; lane 63 keeps 0).
-        const uint32_t next =
-            static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(a), 0x130, 0xF, 0xF, false));
-        const uint32_t p0 = (first + lane) * 4u;
-        uint32_t packed = 0;
-#pragma unroll
-        for (uint32_t k = 0; k < 4u; ++k) {
-            const uint32_t t = (a >> (8u * k)) & 255u;
-            const uint32_t nb = (k < 3u ? a >> (8u * k + 8u) : next) & 255u;
-            const uint32_t lit = t >> 4;
-            uint32_t len = 3u + lit + ((t & 15u) == 15u ? 1u : 0u);
-            len += lit == 15u ? 1u + nb : 0u;
-            len = (lit == 15u && nb >= 236u) || p0 + k > limit ? 0u : len;  // 3 + 15 + 1 + 1 + 236 = 256
-            packed |= len << (8u * k);
-        }
-        lens = packed;
-        lens_first = first;
-        lens_limit = limit;
     }
 
     // The four bytes at byte position `pos` (counted from `aligned`), little-endian.
@@ -181,11 +147,13 @@ struct InputWindow {
     }
 
     // Four staged bytes at `pos`, which any lane may ask for; [pos, pos + 4) is staged.
+    // Two aligned dwords and a funnel shift: an LDS access that is not naturally aligned
+    // occupies the CU's LDS pipeline for 24 clocks instead of 2-3 (tools/ubench_lds_access.hip),
+    // and eight chunks share that pipeline.
     __device__ __forceinline__ uint32_t staged32(uint32_t pos) const
     {
-        uint32_t w;
-        __builtin_memcpy(&w, reinterpret_cast<const uint8_t *>(stage) + (pos - stage_block * 256u), 4);
-        return w;
+        const uint32_t i = (pos >> 2) - stage_block * 64u;
+        return __builtin_amdgcn_alignbit(stage[i + 1u], stage[i], pos << 3);  // shift = 8 (pos & 3)
     }
 };
 
@@ -369,38 +337,6 @@ constexpr uint32_t kHist = 8192;       // bytes of recent output per wave in LDS
 constexpr uint32_t kShortLit = 192;    // longest literal run served from the window registers
 constexpr uint32_t kShortMatch = 512;  // longest match served from the ring
 
-__device__ __forceinline__ uint32_t load32(const uint8_t *p)
-{
-    uint32_t w;
-    __builtin_memcpy(&w, p, 4);  // a dword access at any byte address
-    return w;
-}
-
-__device__ __forceinline__ void store32(uint8_t *p, uint32_t w) { __builtin_memcpy(p, &w, 4); }
-
-// Four ring bytes from output position `pos` on, and the same as a write.
-__device__ __forceinline__ uint32_t ring_read32(const uint8_t *ring, uint32_t pos)
-{
-    const uint32_t i = pos & (kHist - 1u);
-    if (i <= kHist - 4u)
-        return load32(ring + i);
-    uint32_t w = 0;
-    for (uint32_t q = 0; q < 4u; ++q)
-        w |= static_cast<uint32_t>(ring[(i + q) & (kHist - 1u)]) << (8u * q);
-    return w;
-}
-
-__device__ __forceinline__ void ring_write32(uint8_t *ring, uint32_t pos, uint32_t w)
-{
-    const uint32_t i = pos & (kHist - 1u);
-    if (i <= kHist - 4u) {
-        store32(ring + i, w);
-    } else {
-        for (uint32_t q = 0; q < 4u; ++q)
-            ring[(i + q) & (kHist - 1u)] = static_cast<uint8_t>(w >> (8u * q));
-    }
-}
-
 __device__ __forceinline__ void emit_short_literals(const InputWindow &win, uint32_t ip,
                                                     uint32_t lit, uint8_t *out, uint8_t *ring,
                                                     uint32_t op, uint32_t lane)
@@ -469,13 +405,13 @@ constexpr uint32_t kBatchLit = 240;
 // (tuning bits 1-3; the output is then wrong) to see what each costs.
 #ifdef SNAPPY_LZ4_PHASE_SWITCHES
 constexpr uint32_t kPhaseSwitches = 0xEu;
-__device__ unsigned long long g_phase_cycles[9];
+__device__ unsigned long long g_phase_cycles[12];
 struct PhaseClock {
     uint64_t last;
-    uint64_t acc[9];
-    __device__ void start() { last = __builtin_amdgcn_s_memtime(); for (int i = 0; i < 9; ++i) acc[i] = 0; }
+    uint64_t acc[12];
+    __device__ void start() { last = __builtin_amdgcn_s_memtime(); for (int i = 0; i < 12; ++i) acc[i] = 0; }
     __device__ void mark(int phase) { const uint64_t now = __builtin_amdgcn_s_memtime(); acc[phase] += now - last; last = now; }
-    __device__ void flush(uint32_t lane) { if (lane == 0) for (int i = 0; i < 9; ++i) atomicAdd(&g_phase_cycles[i], acc[i]); }
+    __device__ void flush(uint32_t lane) { if (lane == 0) for (int i = 0; i < 12; ++i) atomicAdd(&g_phase_cycles[i], acc[i]); }
 };
 #define PHASE_MARK(clock, phase) (clock).mark(phase)
 #else
@@ -487,29 +423,176 @@ struct PhaseClock {
 #define PHASE_MARK(clock, phase) ((void)0)
 #endif
 constexpr uint32_t kBatchMatch = 255;
-constexpr uint32_t kBatchSpan = 6144;   // most output one batch produces; the ring keeps kHist - kBatchSpan bytes from before it
+// Most output one batch produces, and how far behind a batch's start the ring is still read
+// (kReach).  One wave doing everything: the ring must hold a batch and its reach.  Two
+// waves: the parser already writes the next batch's literals into the ring while the helper
+// copies this batch's matches, so the ring must hold two batches and the reach.
+constexpr uint32_t kSoloSpan = 6144, kSoloReach = 2048;
+constexpr uint32_t kPairSpan = 3072, kPairReach = 2048;
 constexpr uint32_t kBatchInput = 512;   // staged bytes a sequence may touch from its token on
 constexpr uint32_t kLitStep = 8;        // dwords a lane has in flight per step when copying literals
 constexpr uint32_t kMatchStep = 4;      // and matches: a match may repeat a pattern of 16 bytes or more
+constexpr uint32_t kFarStep = 10;       // and matches read from memory: 37 bytes or more per round trip
 
-// The first `count` (at most 4 count) bytes of `w` go to output position `pos` of
-// the ring: a batch's output goes to memory in one piece at its end.  A match's
-// last, partial dword is merged into the four bytes that are there and written
-// back whole (one read, one write, instead of a loop over bytes that the whole
-// wave walks through whenever one lane has such a tail, which is always).  The
-// bytes behind the match that are written back unchanged belong to the next
-// sequence: its literals, which are final by now, or the first dword of its match,
-// which that lane writes whole, before this read or after this write (the two
-// kinds of store are different instructions of the same wave).
-__device__ __forceinline__ void put_ring(uint8_t *ring, uint32_t pos, uint32_t w, uint32_t count)
-{
-    if (count >= 4u) {
-        ring_write32(ring, pos, w);
-    } else if (count != 0u) {
-        const uint32_t mine = 0xFFFFFFFFu >> (8u * (4u - count));
-        const uint32_t old = ring_read32(ring, pos);
-        ring_write32(ring, pos, (w & mine) | (old & ~mine));
+// A lane's copy of n bytes to output position dst of the ring, done with naturally
+// aligned LDS accesses only.  The copy is cut along the dwords of the destination:
+// dword k of the copy is ring dword (dst >> 2) + k, and its bytes come from the source
+// bytes B0 + 4 k .. B0 + 4 k + 3, B0 = src - (dst & 3): the funnel shift (v_alignbyte)
+// of two neighbouring aligned source dwords, S[k] and S[k + 1], by m = B0 & 3 bytes.
+// Dwords that lie wholly inside the copy are stored whole; the first and the last, when
+// they are shared with a neighbouring copy (of another lane, or of another wave), are
+// stored byte by byte, so nothing outside [dst, dst + n) is ever written and nothing is
+// read, modified and written back.  The source may be the staged input, the ring itself
+// (each step reads what the steps before it wrote) or dwords fetched from memory.
+struct LaneCopy {
+    uint32_t d0;        // ring dword number of dword 0 (not yet reduced modulo the ring)
+    uint32_t lead;      // bytes of dword 0 in front of dst
+    uint32_t total;     // lead + n: bytes from dword 0's start to the copy's end (0: nothing to copy)
+    uint32_t count;     // dwords touched
+    uint32_t full_beg;  // dwords [full_beg, full_end) are stored whole
+    uint32_t full_end;
+    int32_t sbase;      // number of the source dword S[0], in the source's own dword numbering
+    uint32_t m;         // bytes to shift
+
+    __device__ __forceinline__ LaneCopy(uint32_t dst, uint32_t n, int32_t src)
+    {
+        d0 = dst >> 2;
+        lead = dst & 3u;
+        total = n ? lead + n : 0u;
+        count = (total + 3u) >> 2;
+        full_beg = lead ? 1u : 0u;
+        full_end = (total & 3u) ? count - 1u : count;
+        const int32_t b0 = src - static_cast<int32_t>(lead);
+        sbase = b0 >> 2;
+        m = static_cast<uint32_t>(b0) & 3u;
     }
+    // Source dword j is wanted by this lane in a step that starts at dword k0.
+    __device__ __forceinline__ bool wants(uint32_t j) const { return j <= count && count != 0u; }
+};
+
+// The stores of one step, dwords 1 .. kStep - 1 of it: lane by lane the dwords to store
+// whole form a run that ends at `rem` (the step's dwords below full_end), so EXEC only
+// ever narrows: one v_cmpx and one ds_write per dword, where the compiler's code for
+// "if (i < rem) at[i] = w[i]" is a compare, a save and a restore of EXEC and a branch
+// around each store.  EXEC is back to what it was when the statement ends.
+#define SNAPPY_LZ4_ST(i, off) "v_cmpx_lt_u32_e32 vcc, " #i ", %[rem]\n\tds_write_b32 %[at], %[w" #i "] offset:" #off "\n\t"
+template <uint32_t kStep>
+__device__ __forceinline__ void store_run(uint32_t at, uint32_t rem, const uint32_t (&w)[kStep])
+{
+    static_assert(kStep == 4u || kStep == 8u || kStep == 10u, "one asm statement per step size");
+    uint64_t save;
+    if constexpr (kStep == 4u) {
+        asm volatile("s_mov_b64 %[save], exec\n\t" SNAPPY_LZ4_ST(1, 4) SNAPPY_LZ4_ST(2, 8) SNAPPY_LZ4_ST(3, 12)
+                     "s_mov_b64 exec, %[save]"
+                     : [save] "=&s"(save)
+                     : [rem] "v"(rem), [at] "v"(at), [w1] "v"(w[1]), [w2] "v"(w[2]), [w3] "v"(w[3])
+                     : "vcc", "memory");
+    } else if constexpr (kStep == 8u) {
+        asm volatile("s_mov_b64 %[save], exec\n\t" SNAPPY_LZ4_ST(1, 4) SNAPPY_LZ4_ST(2, 8) SNAPPY_LZ4_ST(3, 12)
+                     SNAPPY_LZ4_ST(4, 16) SNAPPY_LZ4_ST(5, 20) SNAPPY_LZ4_ST(6, 24) SNAPPY_LZ4_ST(7, 28)
+                     "s_mov_b64 exec, %[save]"
+                     : [save] "=&s"(save)
+                     : [rem] "v"(rem), [at] "v"(at), [w1] "v"(w[1]), [w2] "v"(w[2]), [w3] "v"(w[3]), [w4] "v"(w[4]),
+                       [w5] "v"(w[5]), [w6] "v"(w[6]), [w7] "v"(w[7])
+                     : "vcc", "memory");
+    } else {
+        asm volatile("s_mov_b64 %[save], exec\n\t" SNAPPY_LZ4_ST(1, 4) SNAPPY_LZ4_ST(2, 8) SNAPPY_LZ4_ST(3, 12)
+                     SNAPPY_LZ4_ST(4, 16) SNAPPY_LZ4_ST(5, 20) SNAPPY_LZ4_ST(6, 24) SNAPPY_LZ4_ST(7, 28)
+                     SNAPPY_LZ4_ST(8, 32) SNAPPY_LZ4_ST(9, 36)
+                     "s_mov_b64 exec, %[save]"
+                     : [save] "=&s"(save)
+                     : [rem] "v"(rem), [at] "v"(at), [w1] "v"(w[1]), [w2] "v"(w[2]), [w3] "v"(w[3]), [w4] "v"(w[4]),
+                       [w5] "v"(w[5]), [w6] "v"(w[6]), [w7] "v"(w[7]), [w8] "v"(w[8]), [w9] "v"(w[9])
+                     : "vcc", "memory");
+    }
+}
+#undef SNAPPY_LZ4_ST
+
+// The LDS byte address of a ring position's dword.
+__device__ __forceinline__ uint32_t ring_address(const uint8_t *ring, uint32_t dword)
+{
+    return static_cast<uint32_t>(reinterpret_cast<uintptr_t>((LdsByte *)ring)) + ((dword & (kHist / 4u - 1u)) << 2);
+}
+
+// One step: dwords k0 .. k0 + kStep - 1 from S[0 .. kStep] = source dwords k0 .. k0 + kStep.
+// Most of a batch's instructions are spent here, so: stores go through one base address
+// and constant offsets unless some lane's dwords wrap around the ring's end in this step;
+// the caller's source reads are unconditional (an LDS read of an address the lane has no
+// business with is harmless and cheaper than the exec-mask dance around it).
+template <uint32_t kStep>
+__device__ __forceinline__ void lane_copy_step(uint8_t *ring, const LaneCopy &c, uint32_t k0,
+                                               const uint32_t (&S)[kStep + 1u])
+{
+    uint32_t *ring32 = reinterpret_cast<uint32_t *>(ring);
+    const uint32_t first = (c.d0 + k0) & (kHist / 4u - 1u);
+    uint32_t w[kStep];
+#pragma unroll
+    for (uint32_t i = 0; i < kStep; ++i)
+        w[i] = __builtin_amdgcn_alignbyte(S[i + 1u], S[i], c.m);
+    const int32_t left = static_cast<int32_t>(c.full_end - k0);  // the step's dwords below full_end
+    const uint32_t rem = left > 0 ? static_cast<uint32_t>(left) : 0u;
+    if (__builtin_amdgcn_ballot_w64(first + kStep > kHist / 4u && rem != 0u) == 0) {
+        if (rem != 0u && k0 >= c.full_beg)
+            ring32[first] = w[0];
+        store_run<kStep>(ring_address(ring, first), rem, w);
+    } else {
+#pragma unroll
+        for (uint32_t i = 0; i < kStep; ++i)
+            if (i < rem && (i != 0u || k0 >= c.full_beg))
+                ring32[(first + i) & (kHist / 4u - 1u)] = w[i];
+    }
+    if (k0 == 0u) {
+        // Dword 0's bytes lead .. min(4, total) - 1, when it is not stored whole.  EXEC
+        // narrows from byte 3 down (byte 3 for every lead, byte 2 for leads 1 and 2,
+        // byte 1 for lead 1) unless some lane's copy ends inside dword 0.
+        const uint32_t lead = c.total ? c.lead : 0u;
+        if (__builtin_amdgcn_ballot_w64(lead != 0u && c.total < 4u) == 0) {
+            uint64_t save;
+            uint32_t t;
+            asm volatile("s_mov_b64 %[save], exec\n\t"
+                         "v_cmpx_lt_u32_e32 vcc, 0, %[lead]\n\t"
+                         "v_lshrrev_b32_e32 %[t], 24, %[w]\n\t"
+                         "ds_write_b8 %[at], %[t] offset:3\n\t"
+                         "v_cmpx_gt_u32_e32 vcc, 3, %[lead]\n\t"
+                         "ds_write_b8_d16_hi %[at], %[w] offset:2\n\t"
+                         "v_cmpx_gt_u32_e32 vcc, 2, %[lead]\n\t"
+                         "v_lshrrev_b32_e32 %[t], 8, %[w]\n\t"
+                         "ds_write_b8 %[at], %[t] offset:1\n\t"
+                         "s_mov_b64 exec, %[save]"
+                         : [save] "=&s"(save), [t] "=&v"(t)
+                         : [lead] "v"(lead), [at] "v"(ring_address(ring, c.d0)), [w] "v"(w[0])
+                         : "vcc", "memory");
+        } else {
+            const uint32_t at = (c.d0 * 4u) & (kHist - 1u);
+#pragma unroll
+            for (uint32_t q = 1; q < 4u; ++q)
+                if (lead != 0u && q >= lead && q < c.total)
+                    ring[at + q] = static_cast<uint8_t>(w[0] >> (8u * q));
+        }
+    }
+}
+
+// The last dword's bytes 0 .. (total & 3) - 1, unless dword 0 was the last and has been done.
+// S0, S1: source dwords count - 1 and count.
+__device__ __forceinline__ void lane_copy_tail(uint8_t *ring, const LaneCopy &c, uint32_t S0, uint32_t S1)
+{
+    const uint32_t w_tail = __builtin_amdgcn_alignbyte(S1, S0, c.m);
+    const bool separate = (c.total & 3u) != 0u && c.count - 1u >= c.full_beg;
+    const uint32_t tail = separate ? c.total & 3u : 0u;
+    uint64_t save;
+    uint32_t t;
+    asm volatile("s_mov_b64 %[save], exec\n\t"
+                 "v_cmpx_lt_u32_e32 vcc, 0, %[tail]\n\t"
+                 "ds_write_b8 %[at], %[w]\n\t"
+                 "v_cmpx_lt_u32_e32 vcc, 1, %[tail]\n\t"
+                 "v_lshrrev_b32_e32 %[t], 8, %[w]\n\t"
+                 "ds_write_b8 %[at], %[t] offset:1\n\t"
+                 "v_cmpx_lt_u32_e32 vcc, 2, %[tail]\n\t"
+                 "ds_write_b8_d16_hi %[at], %[w] offset:2\n\t"
+                 "s_mov_b64 exec, %[save]"
+                 : [save] "=&s"(save), [t] "=&v"(t)
+                 : [tail] "v"(tail), [at] "v"(ring_address(ring, c.d0 + c.count - 1u)), [w] "v"(w_tail)
+                 : "vcc", "memory");
 }
 
 // Output positions [beg, end), which the ring holds, go to memory: 16 bytes per lane
@@ -570,73 +653,76 @@ struct BatchInfo {
 // `walk`).  `walk` is how many tokens the next call should look at: a stream of
 // sequences that are not for this code should not pay for 64 tokens walked in vain
 // each time.
+template <typename Team>
 __device__ __forceinline__ uint32_t produce_batch(InputWindow &win, uint32_t &ip_io, uint32_t &op_io,
                                                   uint32_t valid_from, uint32_t iend, uint32_t oend,
                                                   uint32_t &walk, uint32_t lane, PhaseClock &clk,
                                                   BatchLane &desc, BatchInfo &info)
 {
     PHASE_MARK(clk, 5);
-    uint32_t ip = ip_io;  // uniform
+    const uint32_t ip0 = ip_io;  // uniform
     const uint32_t start = op_io;
     const bool likely = walk >= 16u;  // recent batches were worth their while
     const uint32_t ahead = likely ? 3u * kBatchInput : 0u;
-    if (ip < win.stage_block * 256u || ip + kBatchInput + ahead > win.stage_end()) {
+    if (ip0 < win.stage_block * 256u || ip0 + kBatchInput + ahead > win.stage_end()) {
         // Not enough staged for a batch.  Staging more pays when batches have been
         // taken lately; otherwise the one-at-a-time code stages what it needs.
-        if (!likely || ip + kBatchInput > iend)
+        if (!likely || ip0 + kBatchInput > iend)
             return 0;
-        win.restage(ip >> 8, true, lane);
-        win.slide(ip, lane);
+        win.restage(ip0 >> 8, true, lane);
     }
     const uint32_t stage_end = win.stage_end();
 
     PHASE_MARK(clk, 6);
-    // Where the tokens start.
-    uint32_t n = 0;
-    uint32_t my_ip = 0;  // lane j: sequence j
-    // Only what the next token's position depends on is looked at here: the token
-    // and the literal run's extension byte (token_lengths above).  A match length
-    // with more than one extension byte makes the positions from there on
-    // meaningless; the lanes find that out below and the batch ends in front of
-    // such a sequence.  The loop is the decoder's serial part: one v_readlane and
-    // some fifteen scalar instructions per token, four tokens per turn.  The table
-    // says 0 for positions past ip_limit, so the only tests per token are "still
-    // inside the window" and "not 0".  (The same walk in vector registers, with
-    // ds_bpermute for the table look-up, measured 4 % slower.)
+    // Where the tokens start: the decoder's serial part.  Every lane follows the same
+    // chain through the staged bytes in LDS: one read of the token and the byte behind
+    // it (all lanes the same address: a broadcast), the distance to the next token from
+    // those two bytes, the next read.  Nothing else is looked at here: a literal run or
+    // a match with more than one length-extension byte makes the positions from there
+    // on meaningless; the lanes find that out below and the batch ends in front of such
+    // a sequence.  The chain is one LDS round trip and a handful of vector instructions
+    // per token, with no hop through the scalar unit (a walk over a 256-byte register
+    // window with v_readlane took 230 clocks per token plus 620 per window move).
     const uint32_t ip_limit = stage_end - kBatchInput;  // at least kJumpBlocks blocks are staged
     const uint32_t quota = (walk + 3u) & ~3u;           // whole turns; at most 64
-    bool more = ip <= ip_limit;
-    if (more && (win.lens_first != win.first || win.lens_limit != ip_limit))
-        win.token_lengths(ip_limit, lane);
-    while (more) {
-        // A length of 0 (a sequence for the one-at-a-time code starts here, or the staged
-        // input ends) stops the walk where it is: the steps left in the turn find the
-        // same 0 at the same place and change nothing, so one test per turn will do.
-        uint32_t len = 0;
+    uint32_t n = 0;
+    uint32_t my_ip = 0xFFFFFFFFu;  // lane j: sequence j
+    // The chain stays in vector registers: the value is the same in every lane, which
+    // the compiler must not see (the empty asm), or it moves the arithmetic to the scalar
+    // unit and pays a v_readfirstlane, a v_mov and twenty scalar instructions per token.
+    // q is the LDS byte address of the staged byte at position p; bias is a multiple of 4.
+    const uint32_t bias = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((LdsByte *)win.stage)) -
+                          win.stage_block * 256u;
+    const uint32_t q_limit = ip_limit + bias;
+    uint32_t q = ip0 + bias;
+    asm volatile("" : "+v"(q));
+    while (n < quota && uni(q) <= q_limit) {
 #pragma unroll
         for (uint32_t u = 0; u < 4u; ++u) {
-            uint32_t di = (ip >> 2) - win.first;
-            if (__builtin_expect(di >= 63u, 0)) {  // also catches positions before the window
-                win.slide(ip, lane);
-                win.token_lengths(ip_limit, lane);
-                di = 0;
-            }
-            len = (__builtin_amdgcn_readlane(win.lens, di) >> ((ip & 3u) * 8u)) & 255u;
-            my_ip = (lane == n) ? ip : my_ip;
-            n += len != 0u ? 1u : 0u;
-            ip += len;
+            // The token and the byte behind it: two byte reads (aligned whatever q is),
+            // issued together.
+            const LdsByte *a = (const LdsByte *)static_cast<uintptr_t>(q);
+            const uint32_t t = a[0], nb = a[1];
+            const uint32_t lit = t >> 4;
+            const uint32_t ext = lit == 15u ? nb + 1u : 0u;
+            my_ip = (lane == n) ? q : my_ip;
+            ++n;
+            q = q + lit + ext + ((t & 15u) == 15u ? 4u : 3u);
+            asm volatile("" : "+v"(q));
         }
-        more = len != 0u && n < quota;
     }
+    const uint32_t p = q - bias;
+    my_ip -= bias;  // lanes that recorded nothing stay above ip_limit (bias is far below 2^31)
     PHASE_MARK(clk, 0);
     if (n == 0) {
         walk = 4;
         return 0;
     }
 
-    // What each sequence is.
-    const bool walked = lane < n;
-    const uint32_t at = walked ? my_ip : ip_io;
+    // What each sequence is.  A turn's later steps may have left the staged bytes a
+    // sequence may touch: such a position is not taken.
+    const bool walked = lane < n && my_ip <= ip_limit;  // my_ip: 0xFFFFFFFF - bias when nothing was recorded
+    const uint32_t at = walked ? my_ip : ip0;
     const uint32_t r1 = win.staged32(at);
     uint32_t lit = (r1 >> 4) & 15u;
     uint32_t ml = r1 & 15u;
@@ -646,7 +732,7 @@ __device__ __forceinline__ uint32_t produce_batch(InputWindow &win, uint32_t &ip
         lip += 1u;
     }
     uint32_t after = lip + lit;  // the offset; then the next token
-    const uint32_t r2 = win.staged32(after);
+    const uint32_t r2 = win.staged32(walked && lit <= kBatchLit ? after : ip0);
     const uint32_t off = r2 & 0xFFFFu;
     after += 2u;
     if (ml == 15u) {
@@ -659,17 +745,17 @@ __device__ __forceinline__ uint32_t produce_batch(InputWindow &win, uint32_t &ip
     const uint32_t my_op = out_end - out_len;
     const uint32_t mo = my_op + lit;
     const uint32_t s = mo - off;
-    const bool in_ring = s >= valid_from && s + kHist >= start + kBatchSpan;
+    const bool in_ring = s >= valid_from && s + Team::kReach >= start;
     const bool bad = !walked || lit > kBatchLit || ml > kBatchMatch || (off < ml && off < 4u * kMatchStep) ||
                      off > mo || off == 0u || after + 4u > iend || out_end + 16u > oend ||
-                     out_end - start > kBatchSpan || (!in_ring && s + ml > start) ||
+                     out_end - start > Team::kSpan || (!in_ring && s + ml > start) ||
                      (off < ml && !in_ring);
     const uint64_t stop = __builtin_amdgcn_ballot_w64(bad);
     const uint32_t take = stop ? static_cast<uint32_t>(__builtin_ctzll(stop)) : kWave;
     walk = take >= walk ? (2u * walk < kWave ? 2u * walk : kWave) : (take + 4u < kWave ? take + 4u : kWave);
     if (take == 0)
         return 0;
-    ip_io = take < n ? __builtin_amdgcn_readlane(my_ip, take) : ip;
+    ip_io = take < n ? __builtin_amdgcn_readlane(my_ip, take) : uni(p);
     op_io = __builtin_amdgcn_readlane(out_end, take - 1u);
     desc.lip = lip;
     desc.lit = lit;
@@ -687,94 +773,77 @@ __device__ __forceinline__ uint32_t produce_batch(InputWindow &win, uint32_t &ip
     return take;
 }
 
-// Second half: the copies.  The literals come from the staged input (kFromStage:
-// the wave that walked is the one that copies) or from the chunk's input in
-// memory at src_al (another wave copies while the first walks on and may stage
-// something else).
-template <bool kFromStage>
-__device__ __forceinline__ void consume_batch(const InputWindow *win, const uint8_t *src_al, uint8_t *dst,
-                                              uint8_t *ring, const BatchLane &desc, const BatchInfo &info,
-                                              uint32_t lane, uint32_t tuning, PhaseClock &clk)
+// Second half: the copies.  First the literals, every lane its own sequence's, from
+// the staged input into the ring: the wave that walked does this, because it holds the
+// stage (a second wave would have to fetch the same bytes from memory again, a round
+// trip per 32 bytes of literals and twice the traffic).
+__device__ __forceinline__ void batch_literals(const InputWindow &win, uint8_t *ring, const BatchLane &desc,
+                                               const BatchInfo &info, uint32_t lane, uint32_t tuning)
+{
+    if (tuning & kPhaseSwitches & 2u)
+        return;
+    const uint32_t my_lit = lane < info.take ? desc.lit : 0u;
+    const uint32_t my_op = desc.out_end - (desc.lit + desc.ml);
+    // Source positions count bytes from win.aligned, as the stage's dwords do.
+    const LaneCopy c(my_op, my_lit, static_cast<int32_t>(desc.lip));
+    // Lanes with nothing to copy read the stage's first dwords.
+    const uint32_t *src = win.stage + (c.count ? c.sbase - static_cast<int32_t>(win.stage_block * 64u) : 0);
+    for (uint32_t k0 = 0; __builtin_amdgcn_ballot_w64(k0 < c.count) != 0; k0 += kLitStep) {
+        uint32_t S[kLitStep + 1u];
+#pragma unroll
+        for (uint32_t i = 0; i <= kLitStep; ++i)
+            S[i] = src[k0 + i];
+        lane_copy_step<kLitStep>(ring, c, k0, S);
+    }
+    const uint32_t last = c.count ? c.count - 1u : 0u;
+    lane_copy_tail(ring, c, src[last], src[last + 1u]);
+}
+
+// Then the matches, and the batch's output from the ring to memory.  In a pair the
+// helper wave does this while the parser walks on, and the parser may already be
+// writing the next batch's literals into the ring behind info.end.
+template <typename Team>
+__device__ __forceinline__ void batch_matches(uint8_t *dst, uint8_t *ring, const BatchLane &desc,
+                                              const BatchInfo &info, uint32_t lane, uint32_t tuning,
+                                              PhaseClock &clk)
 {
     const uint32_t take = info.take, start = info.start;
     const bool mine = lane < take;
-    const uint32_t lip = desc.lip, lit = desc.lit, ml = desc.ml, off = desc.off;
+    const uint32_t lit = desc.lit, ml = desc.ml, off = desc.off;
     const uint32_t out_end = desc.out_end;
-    const uint32_t my_lit = mine ? lit : 0u;
     const uint32_t my_ml = mine ? ml : 0u;
     const uint32_t my_op = out_end - (lit + ml);
     const uint32_t mo = my_op + lit;
     const uint32_t s = mo - off;
-    const bool in_ring = s >= info.valid_from && s + kHist >= start + kBatchSpan;
+    const bool in_ring = s >= info.valid_from && s + Team::kReach >= start;
 
     // Everything a batch produces is written to the ring only and goes to memory in
     // one piece at the end (flush_ring).  Matches whose source is older than the
-    // batch and out of the ring's reach read memory: their first loads are issued
-    // here, ahead of the literals, which touch LDS alone, so the round trip runs
-    // beside that work.  Every lane loads, from a harmless address when it has
-    // nothing to copy, so that one wait covers a step's loads.
+    // batch and out of the ring's reach read memory, as aligned dwords from the one
+    // that holds the byte that goes to the first ring dword's first byte: their loads
+    // are issued here, ahead of the dependency search below, which touches LDS alone,
+    // so the round trip runs beside that work.  Every lane loads, from a harmless
+    // address when it has nothing to copy, so that one wait covers a step's loads.
     const bool far = mine && !in_ring;
     const bool any_far = !(tuning & kPhaseSwitches & 4u) && __builtin_amdgcn_ballot_w64(far) != 0;
     const uint32_t far_len = far ? ml : 0u;
-    const uint8_t *from = dst + (far ? s : 0u);
-    uint32_t fw[kLitStep];
+    // Dwords below this one hold nothing of the chunk's output (and may lie outside the allocation).
+    const uint32_t *floor32 = reinterpret_cast<const uint32_t *>(reinterpret_cast<uintptr_t>(dst) & ~uintptr_t(3));
+    const uintptr_t from0 = reinterpret_cast<uintptr_t>(dst) + (far ? s : 3u) - (mo & 3u);  // >= dst - 3
+    const uint32_t *from32 = reinterpret_cast<const uint32_t *>(from0 & ~uintptr_t(3));
+    LaneCopy fc(mo, far_len, 0);
+    fc.m = static_cast<uint32_t>(from0) & 3u;
+    uint32_t fw[kFarStep + 1u];
     if (any_far) {
 #pragma unroll
-        for (uint32_t k = 0; k < kLitStep; ++k)
-            fw[k] = load32(from + ((4u * k < far_len) ? 4u * k : 0u));
-    }
-
-    // Literals, whole dwords: up to 3 bytes too many land where the sequence's own
-    // match (4 bytes at least) is written afterwards.
-    bool far_arrived = false;
-    if (!(tuning & kPhaseSwitches & 2u)) {
-        for (uint32_t t = 0; __builtin_amdgcn_ballot_w64(t < my_lit) != 0; t += 4u * kLitStep) {
-            uint32_t w[kLitStep];
-            if (kFromStage) {
-#pragma unroll
-                for (uint32_t k = 0; k < kLitStep; ++k)
-                    if (t + 4u * k < my_lit)
-                        w[k] = win->staged32(lip + t + 4u * k);
-            } else {
-                // From memory, every lane loading (its first literals again when it has none
-                // left), and one wait for the step, which covers the far matches' loads too.
-#pragma unroll
-                for (uint32_t k = 0; k < kLitStep; ++k)
-                    w[k] = load32(src_al + (mine ? lip : 0u) + ((t + 4u * k < my_lit) ? t + 4u * k : 0u));
-                wait_for_memory();
-                far_arrived = true;
-            }
-#pragma unroll
-            for (uint32_t k = 0; k < kLitStep; ++k)
-                if (t + 4u * k < my_lit)
-                    ring_write32(ring, my_op + t + 4u * k, w[k]);
+        for (uint32_t i = 0; i <= kFarStep; ++i) {
+            const uint32_t *at = from32 + (fc.wants(i) ? i : 0u);
+            fw[i] = *(at < floor32 ? floor32 : at);
         }
     }
 
-    PHASE_MARK(clk, 2);
-    // Matches are written to the byte: what follows a match is already in place.
-    bool waiting = mine;
-    if (any_far) {
-        if (!far_arrived)
-            wait_for_memory();
-#pragma unroll
-        for (uint32_t k = 0; k < kLitStep; ++k)
-            put_ring(ring, mo + 4u * k, fw[k], far_len > 4u * k ? far_len - 4u * k : 0u);
-        for (uint32_t t = 4u * kLitStep; __builtin_amdgcn_ballot_w64(t < far_len) != 0; t += 4u * kLitStep) {
-#pragma unroll
-            for (uint32_t k = 0; k < kLitStep; ++k)
-                fw[k] = load32(from + ((t + 4u * k < far_len) ? t + 4u * k : 0u));
-            wait_for_memory();
-#pragma unroll
-            for (uint32_t k = 0; k < kLitStep; ++k)
-                put_ring(ring, mo + t + 4u * k, fw[k], far_len > t + 4u * k ? far_len - (t + 4u * k) : 0u);
-        }
-        waiting = waiting && !far;
-    }
-
-    PHASE_MARK(clk, 3);
-    // Then those that read the ring, in rounds: a match is copied once every match
-    // whose output it reads has been.  These are the sequences from the one that
+    // Matches that read the ring are copied in rounds: a match is copied once every
+    // match whose output it reads has been.  These are the sequences from the one that
     // holds the source's first byte to the last one whose match begins before the
     // source ends (output positions grow with the lane number); a source inside
     // literals alone depends on nothing.  A match that repeats a pattern (offset
@@ -797,27 +866,73 @@ __device__ __forceinline__ void consume_batch(const InputWindow *win, const uint
     const uint64_t below_count = (uint64_t(1) << dep_count) - 1u;
     const uint64_t below_first = (uint64_t(1) << dep_first) - 1u;
     const uint64_t depends_on = below_count & ~below_first;
+    PHASE_MARK(clk, 9);
+
+    // Matches are written to the byte: what follows a match is already in place.
+    bool waiting = mine;
+    if (any_far) {
+        // The last dword's source dwords, for its bytes when it is not stored whole: the
+        // step that holds them keeps them (a step's dwords are registers, not memory).
+        uint32_t t0 = 0, t1 = 0;
+        const uint32_t last = fc.count ? fc.count - 1u : 0u;
+        wait_for_memory();
+#pragma unroll
+        for (uint32_t i = 0; i < kFarStep; ++i) {
+            t0 = (i == last) ? fw[i] : t0;
+            t1 = (i == last) ? fw[i + 1u] : t1;
+        }
+        lane_copy_step<kFarStep>(ring, fc, 0, fw);
+        for (uint32_t k0 = kFarStep; __builtin_amdgcn_ballot_w64(k0 < fc.count) != 0; k0 += kFarStep) {
+#pragma unroll
+            for (uint32_t i = 0; i <= kFarStep; ++i) {
+                const uint32_t *at = from32 + (fc.wants(k0 + i) ? k0 + i : 0u);
+                fw[i] = *(at < floor32 ? floor32 : at);
+            }
+            wait_for_memory();
+#pragma unroll
+            for (uint32_t i = 0; i < kFarStep; ++i) {
+                t0 = (k0 + i == last) ? fw[i] : t0;
+                t1 = (k0 + i == last) ? fw[i + 1u] : t1;
+            }
+            lane_copy_step<kFarStep>(ring, fc, k0, fw);
+        }
+        lane_copy_tail(ring, fc, t0, t1);
+        waiting = waiting && !far;
+    }
+
+    PHASE_MARK(clk, 10);
+    const uint32_t *ring32 = reinterpret_cast<const uint32_t *>(ring);
     for (;;) {
         const uint64_t left = __builtin_amdgcn_ballot_w64(waiting);
         if (left == 0 || (tuning & kPhaseSwitches & 8u))
             break;
         const bool go = waiting && (depends_on & left) == 0;
-        const uint32_t len = go ? my_ml : 0u;
-        for (uint32_t t = 0; __builtin_amdgcn_ballot_w64(t < len) != 0; t += 4u * kMatchStep) {
-            uint32_t w[kMatchStep];
+        const LaneCopy c(mo, go ? my_ml : 0u, static_cast<int32_t>(s));
+        for (uint32_t k0 = 0; __builtin_amdgcn_ballot_w64(k0 < c.count) != 0; k0 += kMatchStep) {
+            // Source dwords through one base address and constant offsets unless some lane's
+            // wrap around the ring's end in this step.
+            uint32_t S[kMatchStep + 1u];
+            const uint32_t first = static_cast<uint32_t>(c.sbase + static_cast<int32_t>(k0)) & (kHist / 4u - 1u);
+            if (__builtin_amdgcn_ballot_w64(first + kMatchStep + 1u > kHist / 4u) == 0) {
 #pragma unroll
-            for (uint32_t k = 0; k < kMatchStep; ++k)
-                if (t + 4u * k < len)
-                    w[k] = ring_read32(ring, s + t + 4u * k);
+                for (uint32_t i = 0; i <= kMatchStep; ++i)
+                    S[i] = ring32[first + i];
+            } else {
 #pragma unroll
-            for (uint32_t k = 0; k < kMatchStep; ++k)
-                put_ring(ring, mo + t + 4u * k, w[k], len > t + 4u * k ? len - (t + 4u * k) : 0u);
+                for (uint32_t i = 0; i <= kMatchStep; ++i)
+                    S[i] = ring32[(first + i) & (kHist / 4u - 1u)];
+            }
+            lane_copy_step<kMatchStep>(ring, c, k0, S);
+        }
+        {
+            const uint32_t last = static_cast<uint32_t>(c.sbase + static_cast<int32_t>(c.count ? c.count - 1u : 0u));
+            lane_copy_tail(ring, c, ring32[last & (kHist / 4u - 1u)], ring32[(last + 1u) & (kHist / 4u - 1u)]);
         }
         waiting = waiting && !go;
     }
     PHASE_MARK(clk, 4);
     flush_ring(dst, ring, start, info.end, lane);
-    PHASE_MARK(clk, 3);
+    PHASE_MARK(clk, 11);
 }
 
 // Who does a chunk's copies.  Solo: the wave that parses, as it goes.  Pair: a
@@ -841,6 +956,7 @@ struct TeamShared {
 };
 
 struct SoloTeam {
+    static constexpr uint32_t kSpan = kSoloSpan, kReach = kSoloReach;
     __device__ __forceinline__ void sync() {}
     __device__ __forceinline__ void copy(uint8_t *dst, const uint8_t *src, uint32_t n, uint32_t lane)
     {
@@ -850,12 +966,14 @@ struct SoloTeam {
                                           const BatchLane &desc, const BatchInfo &info, uint32_t lane,
                                           uint32_t tuning, PhaseClock &clk)
     {
-        consume_batch<true>(&win, nullptr, dst, ring, desc, info, lane, tuning, clk);
+        batch_literals(win, ring, desc, info, lane, tuning);
+        batch_matches<SoloTeam>(dst, ring, desc, info, lane, tuning, clk);
     }
 };
 
 struct PairTeam {
     static constexpr uint32_t kCopyDepth = 4;
+    static constexpr uint32_t kSpan = kPairSpan, kReach = kPairReach;
     TeamShared *sh;
     uint32_t seq;   // commands published so far
     bool pending;   // the helper may still be busy with a batch
@@ -892,10 +1010,15 @@ struct PairTeam {
         wait_for_memory();
         __syncthreads();
     }
-    __device__ __forceinline__ void batch(const InputWindow &, const uint8_t *src_al, uint8_t *dst, uint8_t *,
-                                          const BatchLane &desc, const BatchInfo &info, uint32_t lane, uint32_t,
-                                          PhaseClock &)
+    __device__ __forceinline__ void batch(const InputWindow &win, const uint8_t *src_al, uint8_t *dst, uint8_t *ring,
+                                          const BatchLane &desc, const BatchInfo &info, uint32_t lane,
+                                          uint32_t tuning, PhaseClock &clk)
     {
+        // The literals go into the ring behind the output of the batch the helper may
+        // still be copying (kPairSpan and kPairReach keep the two apart); the barrier in
+        // publish() comes after these LDS writes have completed.
+        batch_literals(win, ring, desc, info, lane, tuning);
+        PHASE_MARK(clk, 2);
         const uint32_t slot = seq & 1u;
         sh->lanes[slot][0][lane] = desc.lip;
         sh->lanes[slot][1][lane] = desc.lit;
@@ -933,7 +1056,7 @@ __device__ void helper_loop(TeamShared *sh, uint8_t *ring, uint32_t lane, uint32
             info.start = uni(sh->info[slot].start);
             info.end = uni(sh->info[slot].end);
             info.valid_from = uni(sh->info[slot].valid_from);
-            consume_batch<false>(nullptr, sh->src[slot], sh->dst[slot], ring, desc, info, lane, tuning, clk);
+            batch_matches<PairTeam>(sh->dst[slot], ring, desc, info, lane, tuning, clk);
             wait_for_memory();  // the flush is in memory before the parser is told so
         } else if (cmd == kCmdCopy) {
             const uint32_t n = uni(sh->len[slot]);
@@ -982,7 +1105,7 @@ __device__ bool decode_sequences(const uint8_t *__restrict__ in_base, uint64_t i
         } else if (!(tuning & 1u)) {
             BatchLane desc;
             BatchInfo info;
-            const uint32_t taken = produce_batch(win, ip, op, valid_from, iend, oend, walk, lane, clk, desc, info);
+            const uint32_t taken = produce_batch<Team>(win, ip, op, valid_from, iend, oend, walk, lane, clk, desc, info);
             if (taken != 0u)
                 team.batch(win, src_al, dst, ring, desc, info, lane, tuning, clk);
             if (taken >= 16u)
@@ -1154,11 +1277,15 @@ lz4_decode_pair_kernel(const uint8_t *__restrict__ in_base, uint64_t in_alloc, u
     __shared__ uint32_t stage[kStageBlocks * 64u];
     __shared__ TeamShared shared;
     const uint32_t lane = threadIdx.x & (kWave - 1);
-    __builtin_amdgcn_s_setprio(3);
+    // The parser's chain of dependent steps is what a chunk's time hangs on: when its
+    // next instruction is ready it goes before the helper's (and both before a SHA-1
+    // kernel's waves in an import).
     if (threadIdx.x >= kWave) {
+        __builtin_amdgcn_s_setprio(2);
         helper_loop(&shared, ring, lane, tuning);
         return;
     }
+    __builtin_amdgcn_s_setprio(3);
     PairTeam team{&shared, 0u, false};
     for (;;) {
         const uint32_t i = wave_claim(queue, 1u, lane);
@@ -1214,7 +1341,7 @@ hipError_t launch_lz4_decode(const uint8_t *d_in, uint64_t in_alloc, uint8_t *d_
         return env ? static_cast<uint32_t>(std::strtoul(env, nullptr, 0)) : 0u;
     }();
 #ifdef SNAPPY_LZ4_PHASE_SWITCHES
-    unsigned long long zero[9] = {};
+    unsigned long long zero[12] = {};
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), zero, sizeof zero);
 #endif
     if (!(tuning & 32u)) {
@@ -1234,10 +1361,11 @@ hipError_t launch_lz4_decode(const uint8_t *d_in, uint64_t in_alloc, uint8_t *d_
     }
 #ifdef SNAPPY_LZ4_PHASE_SWITCHES
     (void)hipStreamSynchronize(stream);
-    unsigned long long c[9];
+    unsigned long long c[12];
     (void)hipMemcpyFromSymbol(c, HIP_SYMBOL(g_phase_cycles), sizeof c);
-    fprintf(stderr, "lz4 phases (s_memtime ticks summed over %u chunks): walk %llu classify %llu literals %llu "
-                    "old sources %llu rounds %llu one-at-a-time %llu staging %llu helper waiting %llu; %llu batches of %.1f sequences\n", n_chunks, c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[8],
+    fprintf(stderr, "lz4 phases (s_memtime ticks summed over %u chunks): parser: walk %llu classify %llu literals %llu "
+                    "between batches and one-at-a-time %llu staging %llu; helper: waiting %llu search and far loads issued %llu "
+                    "far sources %llu rounds %llu flush %llu; %llu batches of %.1f sequences\n", n_chunks, c[0], c[1], c[2], c[5], c[6], c[8], c[9], c[10], c[4], c[11],
             c[7] >> 32, static_cast<double>(c[7] & 0xFFFFFFFFull) / static_cast<double>((c[7] >> 32) ? (c[7] >> 32) : 1));
 #endif
     return hipGetLastError();

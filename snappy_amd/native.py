@@ -11,7 +11,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsnappyhash.so")
+# SNAPPY_LIB_PATH: a variant build of the same library (measurement builds of the tools).
+LIB_PATH = os.environ.get("SNAPPY_LIB_PATH") or os.path.join(_HERE, "libsnappyhash.so")
 
 OK = 0
 E_INVALID_ARG = -1
