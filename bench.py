@@ -208,10 +208,10 @@ def dense_bytes(n: int, rng: np.random.Generator, max_lit: int = 24, max_match: 
 
 
 def make_mcdf_archive(payload_bytes: int, n_files: int, rng: np.random.Generator, tag: str,
-                      content: str = "asset"):
+                      content: str = "asset", body: np.ndarray = None):
     """One synthetic MCDF archive: header JSON + file bodies, lz4net-framed in 1 MiB chunks
     by the library's own compressor (snappy_lz4net_encode).  Returns (stream bytes as uint8
-    array, decoded payload size, payload)."""
+    array, decoded payload size, payload).  `body`: the file bodies, made by the caller."""
     import json as _json
     import struct
 
@@ -223,7 +223,8 @@ def make_mcdf_archive(payload_bytes: int, n_files: int, rng: np.random.Generator
            "Files": [{"GamePaths": [f"chara/{tag}/f{i}.tex"], "Length": int(sz)} for i, sz in enumerate(sizes)]}
     js = _json.dumps(obj, separators=(",", ":")).encode()
     head = b"MCDF\x01" + struct.pack("<i", len(js)) + js
-    body = dense_bytes(payload_bytes, rng) if content == "dense" else asset_like_bytes(payload_bytes, rng)
+    if body is None:
+        body = dense_bytes(payload_bytes, rng) if content == "dense" else asset_like_bytes(payload_bytes, rng)
     payload = np.concatenate([np.frombuffer(head, dtype=np.uint8), body])
     L = native.lib()
     cap = ctypes.c_uint64(0)
@@ -250,18 +251,42 @@ def run_mcdf(args, rank, world, local_rank, dist):
     rng = np.random.default_rng(0x4D434446 + rank)
     n_arch = max(1, int(args.archives))
     content = getattr(args, "mcdf_content", "asset")
+    spec = getattr(args, "mcdf_shape", "uniform") == "spec"
     streams, sizes, first_payload = [], [], None
-    for a in range(n_arch):
-        st, size, payload = make_mcdf_archive(int(args.archive_mib * (1 << 20)), 100, rng, f"r{rank}a{a}", content)
-        streams.append(st)
-        sizes.append(size)
-        if a == 0:
-            first_payload = payload
+    files_per_archive = []
+    if spec:
+        # The configuration as written: archives of 64-512 MiB (uniform), 50-300 files each, half of
+        # them long-run content and half dense short sequences.  The bodies are windows into two
+        # pools of 513 MiB (generating 18 GB of fresh content would take longer than the run).
+        content = "asset and dense, alternating"
+        pools = {"asset": asset_like_bytes((513 << 20), rng), "dense": dense_bytes((513 << 20), rng)}
+        for a in range(n_arch):
+            size = int(rng.integers(64 << 20, (512 << 20) + 1))
+            kind = "asset" if a % 2 == 0 else "dense"
+            start = int(rng.integers(0, pools[kind].size - size + 1))
+            n_files = int(rng.integers(50, 301))
+            st, total, payload = make_mcdf_archive(size, n_files, rng, f"r{rank}a{a}", kind,
+                                                   body=pools[kind][start:start + size])
+            streams.append(st)
+            sizes.append(total)
+            files_per_archive.append(n_files)
+            if a == 0:
+                first_payload = payload
+            del payload
+        del pools
+    else:
+        for a in range(n_arch):
+            st, size, payload = make_mcdf_archive(int(args.archive_mib * (1 << 20)), 100, rng, f"r{rank}a{a}", content)
+            streams.append(st)
+            sizes.append(size)
+            files_per_archive.append(100)
+            if a == 0:
+                first_payload = payload
     comp_bytes = int(sum(s.size for s in streams))
     out_bytes = int(sum(sizes))
     ptrs = (ctypes.c_void_p * n_arch)(*[s.ctypes.data for s in streams])
     lens = np.array([s.size for s in streams], dtype=np.uint64)
-    cap = 100 * n_arch
+    cap = int(sum(files_per_archive))
     digests = np.zeros((cap, 20), dtype=np.uint8)
     statuses = np.zeros(cap, dtype=np.uint8)
     n_files = np.zeros(n_arch, dtype=np.uint64)
@@ -325,15 +350,18 @@ def run_mcdf(args, rank, world, local_rank, dist):
         "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-        "config": {"workload": f"{n_arch} MCDF archives of {args.archive_mib} MiB per GPU: lz4net decode + slice + SHA-1, "
+        "config": {"workload": (f"{n_arch} MCDF archives of 64-512 MiB (uniform), 50-300 files each, per GPU"
+                                if spec else f"{n_arch} MCDF archives of {args.archive_mib} MiB per GPU") +
+                               ": lz4net decode + slice + SHA-1 in one snappy_mcdf_decode_and_hash_batch call, "
                                "compressed streams start in host memory (PCIe copy inside the step)",
+                   "files": cap,
                    "content": content,
                    "compressed_bytes_per_gpu": comp_bytes, "decoded_bytes_per_gpu": out_bytes,
                    "ratio": out_bytes / comp_bytes},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS,
                      "traffic": measured_traffic("mcdf" if content == "asset" else "mcdf_dense", 1.0)
-                     if (n_arch, args.archive_mib) == (8, 256.0) else None,
+                     if (n_arch, args.archive_mib) == (8, 256.0) and not spec else None,
                      "kernel": "lz4_decode_pair_kernel",
                      "kernel_ms": k_lz4, "algorithmic_bytes_per_launch": algo,
                      "launch": "all chunks of all archives in one launch (snappy_lz4net_decode of the archives' "
@@ -342,6 +370,7 @@ def run_mcdf(args, rank, world, local_rank, dist):
                      # Inside the import the decode is split per archive and runs next to the waiting
                      # SHA-1 kernel, behind each archive's transfer; these are those launches' times added up.
                      "import_decode_launches_ms": float(np.mean(lz4_ms)),
+                     "import_decode_launches_over_one_launch": float(np.mean(lz4_ms)) / k_lz4,
                      "sha1_kernel_ms": float(np.mean(sha_ms)),
                      # What a plain device-to-device copy of the decoded size moves on this box (read + write):
                      # the practical ceiling next to the 8 TB/s of the data sheet.
@@ -532,15 +561,25 @@ def extra_workloads(args, lib, native, torch, device, local_rank, n_cu):
     # compressor makes of mesh and texture data).
     class A:
         pass
-    for key, content in (("mcdf_import", "asset"), ("mcdf_import_dense", "dense")):
+    # "mcdf_import_spec" is the configuration as SURVEY 8(d) writes it: 64 archives of 64-512 MiB,
+    # 50-300 files each, both kinds of content, one call; the two 8 x 256 MiB rows are kept beside
+    # it (one kind of content each: the decode kernel's roofline per kind).  Each row carries the
+    # import's CPU baseline: the oracle's scalar decoder + OpenSSL SHA-1, one thread and one
+    # archive per thread.
+    for key, content, shape, n_arch in (("mcdf_import_spec", "asset", "spec", 64), ("mcdf_import", "asset", "uniform", 8),
+                                       ("mcdf_import_dense", "dense", "uniform", 8)):
         a = A()
-        a.archives, a.archive_mib, a.steps, a.warmup, a.no_cpu_baseline, a.mcdf_content = 8, 256.0, 2, 1, True, content
+        a.archives, a.archive_mib, a.steps, a.warmup, a.mcdf_content, a.mcdf_shape = n_arch, 256.0, 2, 1, content, shape
+        a.no_cpu_baseline = getattr(args, "no_cpu_baseline", False)
         m = run_mcdf(a, 0, 1, local_rank, None)
-        res[key] = {"workload": m["config"]["workload"], "content": content, "value": m["value"], "unit": "GB/s",
+        res[key] = {"workload": m["config"]["workload"], "content": m["config"]["content"], "value": m["value"],
+                    "unit": "GB/s", "files": m["config"]["files"],
                     "ms_per_step": m["ms_per_step"], "roofline": m["roofline"],
                     "compressed_bytes": m["config"]["compressed_bytes_per_gpu"],
                     "decoded_bytes": m["config"]["decoded_bytes_per_gpu"],
                     "digests_match_hashlib_sample": m["digests_match_hashlib_sample"]}
+        if "cpu_baseline" in m:
+            res[key]["cpu_baseline"] = m["cpu_baseline"]
     return res
 
 
@@ -775,6 +814,9 @@ def main():
     ap.add_argument("--mcdf-content", default="asset", choices=["asset", "dense"],
                     help="mcdf workload: file bodies of long runs (random, zeros, repeated motifs) or of dense "
                          "short LZ4 sequences (short literal runs between short copies)")
+    ap.add_argument("--mcdf-shape", default="uniform", choices=["uniform", "spec"],
+                    help="mcdf workload: 'spec' = archives of 64-512 MiB (uniform), 50-300 files each, both kinds of "
+                         "content (use with --archives 64)")
     ap.add_argument("--mcdf-decode-only", action="store_true",
                     help="mcdf workload: only the decode kernel, all archives' chunks in one launch (counter passes)")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink or grow the corpus")

@@ -138,11 +138,19 @@ int snappy_sha1_batch_resident(int device, const void *d_base, const uint64_t *d
  * The planner's header and the sorted task list live in a fixed array inside
  * the library (24 MiB + 16 KiB per GPU, held until the process ends) instead of
  * pooled buffers, so the call issues no hipMalloc / hipFree / stream or event
- * creation of its own.  Limits: at most SNAPPY_NOALLOC_MAX_FILES files per call
- * (SNAPPY_E_CAPACITY beyond); snappy_init must have run (the call does not
- * initialise the library); `stream` NULL means the device's default stream.
- * All calls on one GPU share the array: the library makes overlapping calls
- * take turns, and nothing in it survives from one call to the next. */
+ * creation of its own.
+ * ENQUEUE ONLY: unlike snappy_sha1_batch_resident the call does not wait.  It puts
+ * one memset and four kernel launches on `stream` and returns; the digests are
+ * valid once the stream has reached that point (hipStreamSynchronize, an event, or
+ * the replay of a graph the call was captured into).  It may be captured: it
+ * neither synchronises nor allocates.  d_offsets / d_lengths / d_digests are read
+ * and written by the GPU when the work runs, not during the call.
+ * Limits: at most SNAPPY_NOALLOC_MAX_FILES files per call (SNAPPY_E_CAPACITY
+ * beyond); snappy_init must have run (the call does not initialise the
+ * library); `stream` NULL means the device's default stream, which cannot be
+ * captured.  All calls on one GPU share the array and nothing in it survives
+ * from one call to the next: issue them on ONE stream (or order them with
+ * events); work of two calls that overlaps on a GPU races. */
 #define SNAPPY_NOALLOC_MAX_FILES (1u << 20)
 int snappy_sha1_batch_resident_noalloc(int device, const void *d_base,
                                        const uint64_t *d_offsets, const uint64_t *d_lengths,

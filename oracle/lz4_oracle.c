@@ -75,13 +75,10 @@ int oracle_lz4_block_decode(const uint8_t *in, uint64_t in_len, uint8_t *out, ui
         }
         mlen += MINMATCH;
         cpy = op + mlen;
-        /* r7x's tail branch, as recalled (UNVERIFIED, see snappy_oracle.h): a match is
-         * refused when it would write past the end ("cpy > oend") or end exactly at the
-         * end ("op == oend": the last bytes are supposed to be literals).  One that ends
-         * 1-4 bytes short of the end is accepted; the literal rule above then makes the
-         * next sequence end the block.  (Today's liblz4 refuses every match that reaches
-         * into the last 5 bytes; no compressor emits one.) */
-        if (cpy >= out_len)
+        /* LASTLITERALS: the last 5 bytes of a block are literals, so a match that reaches
+         * into them is refused ("cpy > oend - LASTLITERALS" in the r7x decoder lz4net ports,
+         * as recalled, and in today's liblz4).  No compressor emits such a match. */
+        if (cpy + 5 > out_len)
             return ORACLE_E_LZ4_CORRUPT;
         /* Byte-serial copy: offset < mlen repeats the pattern. */
         for (uint64_t i = 0; i < mlen; ++i)

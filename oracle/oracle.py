@@ -255,13 +255,27 @@ def mcdf_parse_header(payload: bytes):
     return version, data, 9 + data_len
 
 
+def simple_upper(ch: str) -> str:
+    """Simple (one code point to one code point) upper-case mapping of one character, as .NET's
+    ordinal casing uses it: str.upper() when that is a single character; the Greek letters with
+    iota subscript, whose full mapping is two letters, go to their single titlecase letter (the
+    UnicodeData.txt simple mapping); U+0131 (dotless i) stays, as in .NET's invariant casing."""
+    cp = ord(ch)
+    if cp == 0x0131:
+        return ch
+    if 0x1F80 <= cp <= 0x1FAF and (cp & 0xF) < 8:
+        return chr(cp + 8)
+    if cp in (0x1FB3, 0x1FC3, 0x1FF3):
+        return chr(cp + 9)
+    u = ch.upper()
+    return u if len(u) == 1 else ch
+
+
 def _ordinal_upper(s: str) -> str:
-    """Key folding of StringComparer.OrdinalIgnoreCase: simple per-char upper-casing."""
-    out = []
-    for ch in s:
-        u = ch.upper()
-        out.append(u if len(u) == 1 else ch)
-    return "".join(out)
+    """Key folding of StringComparer.OrdinalIgnoreCase (Models/SnapshotInfo.cs:11-12,
+    Features/Mcdf/McdfManager.cs:34): simple per-character upper-casing, supplementary-plane
+    letters included."""
+    return "".join(simple_upper(ch) for ch in s)
 
 
 def mcdf_extract_and_hash(files, payload: bytes, body_offset: int):

@@ -33,9 +33,9 @@
  *      an error; a clean end only at a chunk boundary) is lz4net's as recalled.
  *   2. The block decoder's acceptance of malformed input follows LZ4 r7x
  *      LZ4_uncompress as recalled: a literal run ending within 8 bytes of the end
- *      must end the block; a match is refused when it would write past the end or
- *      end exactly at it, and accepted when it ends 1-4 bytes short (today's
- *      liblz4 refuses those too).  Valid compressor output never meets either rule.
+ *      must end the block; a match that reaches into the last 5 bytes of the
+ *      block is refused (LASTLITERALS, as in today's liblz4).  Valid compressor
+ *      output never meets either rule.
  *   3. The MCDF header is read with a strict JSON reader.  Newtonsoft also takes
  *      comments, single-quoted strings and unquoted names, and coerces a number or
  *      bool given for a string property; those inputs are refused here

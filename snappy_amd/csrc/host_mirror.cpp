@@ -31,6 +31,7 @@
 #include <thread>
 #include <vector>
 
+#include "unicode_upper_table.hpp"
 #include "../../include/snappyhash.h"
 #include "mcdf_host.hpp"
 #include "runtime.hpp"
@@ -52,13 +53,75 @@ bool write_all_bytes(const std::string &path, const uint8_t *data, size_t n)
     return static_cast<bool>(f);
 }
 
-// Key folding of StringComparer.OrdinalIgnoreCase, ASCII range (game paths are ASCII).
+// Simple upper-case mapping of one code point (unicode_upper_table.hpp; ASCII done here).
+uint32_t simple_upper(uint32_t cp)
+{
+    if (cp < 0x80u)
+        return (cp >= 'a' && cp <= 'z') ? cp - 'a' + 'A' : cp;
+    const UpperPair *lo = kSimpleUpper, *hi = kSimpleUpper + sizeof(kSimpleUpper) / sizeof(kSimpleUpper[0]);
+    while (lo < hi) {
+        const UpperPair *mid = lo + (hi - lo) / 2;
+        if (mid->from < cp)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    const UpperPair *end = kSimpleUpper + sizeof(kSimpleUpper) / sizeof(kSimpleUpper[0]);
+    return (lo < end && lo->from == cp) ? lo->to : cp;
+}
+
+void append_utf8(std::string &out, uint32_t cp)
+{
+    if (cp < 0x80u) {
+        out.push_back(static_cast<char>(cp));
+    } else if (cp < 0x800u) {
+        out.push_back(static_cast<char>(0xC0u | (cp >> 6)));
+        out.push_back(static_cast<char>(0x80u | (cp & 0x3Fu)));
+    } else if (cp < 0x10000u) {
+        out.push_back(static_cast<char>(0xE0u | (cp >> 12)));
+        out.push_back(static_cast<char>(0x80u | ((cp >> 6) & 0x3Fu)));
+        out.push_back(static_cast<char>(0x80u | (cp & 0x3Fu)));
+    } else {
+        out.push_back(static_cast<char>(0xF0u | (cp >> 18)));
+        out.push_back(static_cast<char>(0x80u | ((cp >> 12) & 0x3Fu)));
+        out.push_back(static_cast<char>(0x80u | ((cp >> 6) & 0x3Fu)));
+        out.push_back(static_cast<char>(0x80u | (cp & 0x3Fu)));
+    }
+}
+
+// Key folding of StringComparer.OrdinalIgnoreCase (Snappy/Models/SnapshotInfo.cs:11-12,
+// Snappy/Features/Mcdf/McdfManager.cs:34): every character goes to its simple upper-case
+// mapping, letters outside ASCII and outside the BMP included ("chara/\u00e9.tex" and
+// "CHARA/\u00c9.TEX" are one key).  Keys are UTF-8 here; bytes that are not well-formed
+// UTF-8 are kept as they are.
 std::string fold_key(const std::string &s)
 {
-    std::string k = s;
-    for (char &c : k)
-        if (c >= 'a' && c <= 'z')
-            c = static_cast<char>(c - 'a' + 'A');
+    std::string k;
+    k.reserve(s.size());
+    const size_t n = s.size();
+    for (size_t i = 0; i < n;) {
+        const unsigned char c = static_cast<unsigned char>(s[i]);
+        if (c < 0x80u) {
+            k.push_back((c >= 'a' && c <= 'z') ? static_cast<char>(c - 'a' + 'A') : static_cast<char>(c));
+            ++i;
+            continue;
+        }
+        const size_t len = c >= 0xF0u ? 4 : c >= 0xE0u ? 3 : c >= 0xC0u ? 2 : 1;
+        uint32_t cp = len == 4 ? c & 0x07u : len == 3 ? c & 0x0Fu : c & 0x1Fu;
+        bool ok = len > 1 && i + len <= n && c < 0xF8u;
+        for (size_t q = 1; ok && q < len; ++q) {
+            const unsigned char t = static_cast<unsigned char>(s[i + q]);
+            ok = (t & 0xC0u) == 0x80u;
+            cp = (cp << 6) | (t & 0x3Fu);
+        }
+        if (!ok) {
+            k.push_back(static_cast<char>(c));
+            ++i;
+            continue;
+        }
+        append_utf8(k, simple_upper(cp));
+        i += len;
+    }
     return k;
 }
 

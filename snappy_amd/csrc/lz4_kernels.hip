@@ -19,8 +19,8 @@
 //
 // Acceptance rules are those of the decoder lz4net ports (LZ4 r7x
 // LZ4_uncompress with a known output length, as recalled): a literal run that
-// ends within 8 bytes of the end must end the block exactly; a match must end
-// before the end of the block (not at it); consumed input must equal the chunk's
+// ends within 8 bytes of the end must end the block exactly; a match must end at
+// least 5 bytes before the end of the block; consumed input must equal the chunk's
 // compressed length.  Every read and write is bounds-checked against the chunk, so a
 // corrupt stream yields a status word, never a stray access.
 #include "lz4_launch.hpp"
@@ -1199,10 +1199,9 @@ __device__ bool decode_sequences(const uint8_t *__restrict__ in_base, uint64_t i
             }
         }
         ml += 4u;
-        // r7x refuses a match that would write past the end or end exactly at it (the
-        // last bytes are supposed to be literals); one that ends 1-4 bytes short is taken,
-        // and the literal rule above makes the next sequence end the block.
-        if (ml >= oend - op)
+        // The last five bytes of a block are literals: a match that reaches into them is
+        // refused (LZ4's LASTLITERALS rule, in the r7x decoder lz4net ports as in today's).
+        if (ml + 5u > oend - op)
             return false;
 
         if (ml <= kShortMatch && offset <= kHist - kShortMatch && op - offset >= valid_from) {

@@ -238,7 +238,7 @@ int import_batch_overlapped(SlotLease &lease, std::vector<StreamJob> &jobs, std:
     // sequences takes milliseconds (long copies: 0.3 ms).  Next to a resident SHA-1
     // kernel only half as many decoder waves fit on a CU, so decoding such archives
     // behind their transfers one by one would hold the later ones back by more than
-    // the overlap gains.  When one chunk takes longer than an archive's transfer, the
+    // the overlap gains.  When one chunk takes much longer than an archive's transfer, the
     // order stays the plain one: send everything, decode everything in one launch with
     // the GPU to itself, then hash (the headers read above are not read again).
     uint64_t mean_stream = 0;
@@ -250,7 +250,21 @@ int import_batch_overlapped(SlotLease &lease, std::vector<StreamJob> &jobs, std:
         mean_chunk += c.orig_len / firsts.size();
     const float whole_chunk_ms =
         first_chunks_ms * (mean_chunk > kHeaderPrefix ? static_cast<float>(mean_chunk) / kHeaderPrefix : 1.f);
-    if (!order.empty() && whole_chunk_ms > static_cast<float>(mean_stream) / 50e6f) {
+    // (Decodes run on a stream of their own, beside the following transfers, in runs of up to
+    // eight archives: only a chunk that takes several archives' transfers puts them behind.)
+    // The waiting kernel hands its files out largest first over the whole batch, whatever
+    // archive they belong to: with many archives most waves soon hold a file of an archive
+    // that is still to come and sit on it while files that have arrived go unclaimed, and the
+    // import takes transfers plus hashing instead of the longer of the two.  The overlap pays
+    // when the transfers are short next to the largest file's chain (0.72 us per 64-byte
+    // block), which then runs beside nearly all of them; otherwise the plain order is as fast.
+    uint64_t largest_file = 0;
+    for (uint64_t v : lengths)
+        largest_file = std::max(largest_file, v);
+    const float chain_ms = static_cast<float>(largest_file / 64u) * 0.72e-3f;
+    const float all_transfers_ms = static_cast<float>(stream_bytes) / 50e6f;
+    const bool overlap_pays = all_transfers_ms <= 0.35f * chain_ms || std::getenv("SNAPPY_MCDF_FORCE_OVERLAP") != nullptr;
+    if (!order.empty() && (!overlap_pays || whole_chunk_ms > 4.f * static_cast<float>(mean_stream) / 50e6f)) {
         std::vector<Piece> all;
         for (size_t a = 0; a < n; ++a)  // arena order
             if (!jobs[a].dropped && jobs[a].in_len)
@@ -294,7 +308,7 @@ int import_batch_overlapped(SlotLease &lease, std::vector<StreamJob> &jobs, std:
                 (void)hipEventDestroy(e);
         }
     } destroy_events{marks};
-    for (size_t k = 0; k < 2 * order.size(); ++k) {
+    for (size_t k = 0; k < 3 * order.size(); ++k) {  // per archive: transfers enqueued, decode begins, decode ends
         hipEvent_t e;
         SNAPPY_HIP_TRY(hipEventCreate(&e));
         marks.push_back(e);
@@ -335,66 +349,68 @@ int import_batch_overlapped(SlotLease &lease, std::vector<StreamJob> &jobs, std:
 
     // 4. The archives: copy, decode, raise the counter.  From here on a kernel may be
     // waiting: whatever goes wrong, it has to be told.
-    // An archive's decode sits between its transfer and the next one's on the copy
-    // stream.  That is the right order while a decode is short next to a transfer
-    // (long copies: 0.3 ms against 3).  On streams of short sequences one archive's
-    // 256 chunks take as long as 2048 would (a chunk's own chain of sequences decides,
-    // some 8 ms), and eight of them in a row would hold every later archive back: when
-    // a decode has taken longer than the transfer that followed it, the remaining
-    // archives are sent first and decoded by one launch.
+    // The transfers follow each other on the copy stream.  The decodes go to a stream of
+    // their own, each behind the transfers it needs (an event), so that a decode runs
+    // beside the next archives' transfers instead of between them, and the host thread,
+    // which waits for the copy stream when it feeds pageable memory through the ring,
+    // does not wait for decodes.  A decode launch lasts as long as one chunk's chain of
+    // sequences, however few chunks it has (0.3 ms on long copies, 3 ms on dense short
+    // sequences), so archives are decoded in runs: the first archive alone (it holds the
+    // largest file, whose SHA-1 chain decides when the import ends), the others in runs
+    // of `run_len`, larger where a chunk takes long next to an archive's transfer.
     hipError_t failure = hipSuccess;
     std::vector<std::pair<size_t, size_t>> launches;  // (first, last + 1) positions in `order` per decode launch
-    bool grouped = false;
-    size_t group_from = 0;
+    const float transfer_ms = static_cast<float>(mean_stream) / 50e6f;  // one archive at PCIe rate
+    size_t run_len = 1;
+    if (whole_chunk_ms > 0.25f * transfer_ms)
+        run_len = std::min<size_t>(8, static_cast<size_t>(4.f * whole_chunk_ms / (transfer_ms > 0.f ? transfer_ms : 1.f)) + 1);
+    if (const char *v = std::getenv("SNAPPY_MCDF_DECODE_RUN"))  // tuning
+        run_len = std::max<size_t>(1, std::strtoul(v, nullptr, 10));
     auto decode_run = [&](size_t from, size_t to) -> hipError_t {
         const uint32_t rows = static_cast<uint32_t>(first_row[to] - first_row[from]);
-        hipError_t e = hipSuccess;
-        if (rows) {
-            e = hipEventRecord(marks[2 * from], s.copy_stream);
+        // The run's last transfer has been enqueued: everything up to here on the copy stream.
+        hipError_t e = hipEventRecord(marks[3 * from + 2], s.copy_stream);
+        if (e == hipSuccess)
+            e = hipStreamWaitEvent(s.decode_stream, marks[3 * from + 2], 0);
+        if (e == hipSuccess && rows) {
+            e = hipEventRecord(marks[3 * from], s.decode_stream);
             if (e == hipSuccess)
                 e = launch_lz4_decode(arena, plan.in_alloc, arena, d_table + first_row[from], rows,
                                       d_queue + 16u * from, d_status + first_row[from], lease.dev->n_cu,
-                                      s.copy_stream);
+                                      s.decode_stream);
             if (e == hipSuccess)
-                e = hipEventRecord(marks[2 * from + 1], s.copy_stream);
+                e = hipEventRecord(marks[3 * from + 1], s.decode_stream);
             if (e == hipSuccess)
                 launches.emplace_back(from, to);
         }
         if (e == hipSuccess && n_files)
             e = hipMemcpyAsync(&d_arrival->arrived, &numbers[to - 1], sizeof(uint32_t), hipMemcpyHostToDevice,
-                               s.copy_stream);
+                               s.decode_stream);
         return e;
     };
+    size_t run_from = 0;
     for (size_t k = 0; k < order.size() && failure == hipSuccess; ++k) {
         const size_t a = order[k];
         std::vector<Piece> whole{{jobs[a].in, jobs[a].in_off, jobs[a].in_len}};
         failure = transfer_to_device(s, hip_device, whole, kTransferSliceBytes, arena, nullptr, nullptr);
         if (failure != hipSuccess)
             break;
-        if (!grouped && k > 0 && !launches.empty() && launches.back().second == k) {
-            // The previous archive's decode lay ahead of this transfer on the stream: it is over.
-            float decode_ms = 0.f;
-            const size_t prev = launches.back().first;
-            if (hipEventElapsedTime(&decode_ms, marks[2 * prev], marks[2 * prev + 1]) != hipSuccess)
-                (void)hipGetLastError();
-            const float transfer_ms = static_cast<float>(jobs[a].in_len) / 50e6f;  // at PCIe rate
-            if (decode_ms > 1.5f * transfer_ms && k + 1 < order.size()) {
-                grouped = true;
-                group_from = k;
-            }
+        const bool run_ends = k == 0 || k + 1 == order.size() || k + 1 - run_from >= run_len;
+        if (run_ends) {
+            failure = decode_run(run_from, k + 1);
+            run_from = k + 1;
         }
-        if (!grouped)
-            failure = decode_run(k, k + 1);
     }
-    if (grouped && failure == hipSuccess)
-        failure = decode_run(group_from, order.size());
     if (failure == hipSuccess)
         failure = hipStreamSynchronize(s.copy_stream);
+    if (failure == hipSuccess)
+        failure = hipStreamSynchronize(s.decode_stream);
     if (failure != hipSuccess) {
         set_error_detail(std::string("MCDF import, transfer or decode: ") + hipGetErrorString(failure));
         (void)hipGetLastError();
         const uint32_t one = 1;
         (void)hipMemcpy(&d_arrival->abort, &one, sizeof(one), hipMemcpyHostToDevice);
+        (void)hipStreamSynchronize(s.decode_stream);
         (void)hipStreamSynchronize(s.stream);  // the kernel leaves on abort (or on its own time limit)
         return SNAPPY_E_HIP;
     }
@@ -421,7 +437,7 @@ int import_batch_overlapped(SlotLease &lease, std::vector<StreamJob> &jobs, std:
         float total_ms = 0.f;
         for (const auto &run : launches) {
             float ms = 0.f;
-            if (hipEventElapsedTime(&ms, marks[2 * run.first], marks[2 * run.first + 1]) == hipSuccess)
+            if (hipEventElapsedTime(&ms, marks[3 * run.first], marks[3 * run.first + 1]) == hipSuccess)
                 total_ms += ms;
             else
                 (void)hipGetLastError();

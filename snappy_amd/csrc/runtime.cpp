@@ -26,6 +26,7 @@ int create_slot(Slot &s)
 {
     SNAPPY_HIP_TRY(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
     SNAPPY_HIP_TRY(hipStreamCreateWithFlags(&s.copy_stream, hipStreamNonBlocking));
+    SNAPPY_HIP_TRY(hipStreamCreateWithFlags(&s.decode_stream, hipStreamNonBlocking));
     // Uncached on the device, so that a running kernel sees what a copy engine wrote.
     if (hipExtMallocWithFlags(&s.d_flags, 256, hipDeviceMallocFinegrained) != hipSuccess) {
         (void)hipGetLastError();
@@ -57,6 +58,8 @@ void destroy_slot(Slot &s)
                 (void)hipEventDestroy(s.ev_prof[k][j]);
     if (s.d_flags)
         (void)hipFree(s.d_flags);
+    if (s.decode_stream)
+        (void)hipStreamDestroy(s.decode_stream);
     if (s.copy_stream)
         (void)hipStreamDestroy(s.copy_stream);
     if (s.stream)

@@ -67,6 +67,7 @@ constexpr int kProfileKernels = 2;  // 0 = SHA-1, 1 = LZ4 decode
 struct Slot {
     hipStream_t stream = nullptr;      // main stream of the call
     hipStream_t copy_stream = nullptr; // host -> device transfers that overlap the kernels
+    hipStream_t decode_stream = nullptr; // MCDF import: decode launches behind the transfers, beside the next ones
     void *d_flags = nullptr;           // 256 bytes of fine-grained device memory (progress words)
     hipEvent_t ev_prof[kProfileKernels][2] = {};
     Buffer d_data;     // device arena for host-pointer calls

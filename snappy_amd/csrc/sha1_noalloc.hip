@@ -1,5 +1,9 @@
 // snappy_sha1_batch_resident for callers that cannot allocate: code under HIP
-// graph capture, tight serving loops, harnesses that forbid hipMalloc.
+// graph capture, tight serving loops, harnesses that forbid hipMalloc.  Unlike the
+// entry point it is a variant of, it only ENQUEUES: a memset and four kernel
+// launches on the caller's stream, no allocation, no synchronisation, no wait.  The
+// digests are there when the stream reaches that point; the caller synchronises (or
+// captures the call into a graph and replays it).
 //
 // snappy_sha1_batch_resident keeps its planning area (the planner's header and
 // the size-sorted task list, sha1_plan.hip) in pooled device buffers that grow
@@ -31,8 +35,10 @@ constexpr size_t kScratchBytes = kStateBytes + kNoAllocMaxFiles * sizeof(Sha1Tas
 static __device__ __align__(256) unsigned char scratch[kScratchBytes];
 
 constexpr int kMaxHipDevices = 64;
-// Device address of `scratch` on each HIP device (null until set up), and the
-// lock that makes overlapping calls on one GPU take turns: they share the array.
+// Device address of `scratch` on each HIP device (null until set up).  Calls on one
+// GPU share the array, so their work must not overlap on the device: the caller
+// issues them on one stream (or orders them by events).  The lock below only keeps
+// two host threads from interleaving their launches; it is not held while the GPU works.
 unsigned char *g_scratch_ptr[kMaxHipDevices] = {};
 std::mutex g_scratch_mu[kMaxHipDevices];
 
@@ -89,7 +95,11 @@ extern "C" int snappy_sha1_batch_resident_noalloc(int device, const void *d_base
             set_error_detail("the planning area of this device was not set up");
             return SNAPPY_E_HIP;
         }
-        SNAPPY_HIP_TRY(hipSetDevice(hip_device));
+        // No hipSetDevice unless it changes something (the call may sit inside a capture).
+        int current = -1;
+        SNAPPY_HIP_TRY(hipGetDevice(&current));
+        if (current != hip_device)
+            SNAPPY_HIP_TRY(hipSetDevice(hip_device));
 
         unsigned char *area = g_scratch_ptr[hip_device];
         Sha1PlanState *d_state = reinterpret_cast<Sha1PlanState *>(area);
@@ -106,7 +116,6 @@ extern "C" int snappy_sha1_batch_resident_noalloc(int device, const void *d_base
         const int launch_rounds = (n >= 128ull * n_simd) ? kMaxWavesPerSimd : 1;
         SNAPPY_HIP_TRY(launch_sha1_hop(static_cast<const uint8_t *>(d_base), d_tasks, d_state, d_digests,
                                        nullptr, n32, n_simd, launch_rounds, s));
-        SNAPPY_HIP_TRY(hipStreamSynchronize(s));
-        return SNAPPY_OK;
+        return SNAPPY_OK;  // enqueued, not finished
     });
 }

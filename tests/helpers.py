@@ -153,22 +153,13 @@ def good_block_vectors():
         "chained_overlap": block([(b"ab", 2, 6), (b"", 1, 5), (b"c", 4, 30), (b"", 9, 100),
                                   (b"12345", None, None)]),
     }
-    # A match that ends 1-4 bytes before the end of the block, followed by that many final
-    # literals.  No compressor writes this (the format asks for 5 final literals) and today's
-    # liblz4 refuses it; the decoder lz4net ports (LZ4 r7x LZ4_uncompress, as recalled: its
-    # tail branch only refuses "cpy > oend" and "op == oend") accepts it, and so do the oracle
-    # and the kernel.  UNVERIFIED against lz4net itself: these vectors make the choice explicit.
-    for tail in (1, 2, 3, 4):
-        vecs[f"match_ends_{tail}_before_end"] = block([(b"a", 1, 10), (b"wxyz"[:tail], None, None)])
-        vecs[f"long_match_ends_{tail}_before_end"] = block([(splitmix_bytes(40, 60 + tail), 33, 700),
-                                                            (b"wxyz"[:tail], None, None)])
     return vecs
 
 
 def bad_block_vectors():
     """(block_bytes, claimed_output_len) pairs every conforming decoder must reject."""
     good, out = block([(b"a", 1, 10), (b"bcdef", None, None)])
-    return {
+    vecs = {
         "match_ends_at_end": (seq(b"a", 1, 10), 11),                       # r7x: "op == oend" after a match
         "match_ends_at_end_then_empty_literals": (seq(b"a", 1, 10) + seq(b""), 11),
         "match_past_end": (seq(b"a", 1, 10) + seq(b"bcde"), 10),
@@ -186,6 +177,17 @@ def bad_block_vectors():
         "offset_cut": (seq(b"abcd", 4, 8)[:-1], 17),
         "huge_literal_claim": (b"\xf0" + b"\xff" * 8 + b"\x00", 64),
     }
+    # A match that reaches into the last 5 bytes of the block (it ends 1-4 bytes before the
+    # end, followed by that many final literals).  No compressor writes this; today's liblz4
+    # refuses it and so does the LASTLITERALS test of the r7x decoder that lz4net ports (as
+    # recalled: nothing here can check lz4net itself).
+    for tail in (1, 2, 3, 4):
+        for name, parts in ((f"match_into_last5_{tail}", [(b"a", 1, 10), (b"wxyz"[:tail], None, None)]),
+                            (f"long_match_into_last5_{tail}", [(splitmix_bytes(40, 60 + tail), 33, 700),
+                                                               (b"wxyz"[:tail], None, None)])):
+            data, out = block(parts)
+            vecs[name] = (data, len(out))
+    return vecs
 
 
 # ----------------------------------------------------------------- lz4net framing

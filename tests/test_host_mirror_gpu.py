@@ -80,6 +80,10 @@ def test_import_mcdf_writes_reference_layout(snappy, oracle, tmp_path):
             paths.append("chara/shared.tex")
         if i == 9:
             paths.append("CHARA/SHARED.TEX")      # folds onto i == 7's key: last writer wins
+        if i == 10:                               # letters outside ASCII and outside the BMP fold too
+            paths += ["chara/caf\u00e9.tex", "chara/\u0436\u0443\u043a.tex", "chara/\U00010428.tex", "chara/fu\u00df.tex"]
+        if i == 11:
+            paths += ["CHARA/CAF\u00c9.TEX", "CHARA/\u0416\u0423\u041a.TEX", "CHARA/\U00010400.TEX", "CHARA/FUSS.TEX"]
         files.append((paths, body, n))
     payload = oracle.build_mcdf_payload("My Import", files,
                                         extra={"ManipulationData": "bWFuaXA=", "GlamourerData": "glam\"quoted\""})
@@ -106,6 +110,9 @@ def test_import_mcdf_writes_reference_layout(snappy, oracle, tmp_path):
     assert info["ManipulationString"] == "bWFuaXA="
     assert info["FileReplacements"] == ref["map"]
     assert list(info["FileReplacements"]) == list(ref["map"])      # Dictionary insertion order
+    assert "chara/caf\u00e9.tex" in info["FileReplacements"] and "CHARA/CAF\u00c9.TEX" not in info["FileReplacements"]
+    assert "chara/\U00010428.tex" in info["FileReplacements"] and "CHARA/\U00010400.TEX" not in info["FileReplacements"]
+    assert "chara/fu\u00df.tex" in info["FileReplacements"] and "CHARA/FUSS.TEX" in info["FileReplacements"]
     assert info["LastUpdate"].endswith("Z") and len(info["LastUpdate"]) == 28
     glam = json.load(open(os.path.join(out, "glamourer_history.json")))
     assert glam["Entries"][0]["GlamourerString"] == 'glam"quoted"'
@@ -259,10 +266,20 @@ def test_update_snapshot_matches_the_reference_loop(snappy, oracle, tmp_path):
              (paths[2], ["chara/b.tex"]),
              (paths[3], ["chara/c.tex", 'chara/quo"te.tex']),
              (paths[5], ["chara/b_copy.tex"]),                     # duplicate content: one .dat
-             (paths[4], ["chara/b.tex"])]                          # same game path again: last hash wins
+             (paths[4], ["chara/b.tex"]),                          # same game path again: last hash wins
+             # OrdinalIgnoreCase folds letters outside ASCII too (simple upper-case mapping per
+             # character, supplementary planes included); sharp s has no single-letter upper case
+             (paths[1], ["chara/\u00e9t\u00e9.tex", "chara/stra\u00dfe.tex", "chara/\u043f\u0440\u0438\u0432\u0435\u0442.tex",
+                         "chara/\U00010428.tex", "chara/\u0131.tex", "chara/\u1f80.tex"])]
     second = [(paths[6], ["CHARA/A.tex"]),                         # folds onto chara/a.tex: spelling kept, hash replaced
               (paths[7], ["chara/new.mdl"]),
-              (paths[2], ["chara/b.tex"])]
+              (paths[2], ["chara/b.tex"]),
+              (paths[6], ["CHARA/\u00c9T\u00c9.TEX",                   # one key with chara/été.tex
+                          "CHARA/STRASSE.TEX",                      # NOT the key of straße: a new entry
+                          "CHARA/\u041f\u0420\u0418\u0412\u0415\u0422.TEX",   # Cyrillic capitals: one key with привет
+                          "CHARA/\U00010400.TEX",                  # Deseret capital long I: one key with U+10428
+                          "CHARA/I.TEX",                           # dotless i does not fold onto I: a new entry
+                          "CHARA/\u1f88.TEX"])]                    # Greek alpha psili prosgegrammeni: folds onto U+1F80
     ours, theirs = tmp_path / "ours" / "Hero", tmp_path / "theirs" / "Hero"
     for replacements, glam, cplus, manip in ((first, "glam-1", '{"Bones":{}}', "manip-1"),
                                             (second, "glam-1", '{"Bones":{"j_kao":{}}}', "manip\u2028two"),
@@ -280,6 +297,14 @@ def test_update_snapshot_matches_the_reference_loop(snappy, oracle, tmp_path):
     info = json.load(open(ours / "snapshot.json"))
     assert list(info["FileReplacements"])[:2] == ["chara/empty.tex", "chara/a.tex"]
     assert info["FileReplacements"]["chara/a.tex"] == hashlib.sha1(blobs[6]).hexdigest().upper()
+    keys = list(info["FileReplacements"])
+    for kept, absent in (("chara/\u00e9t\u00e9.tex", "CHARA/\u00c9T\u00c9.TEX"),
+                         ("chara/\u043f\u0440\u0438\u0432\u0435\u0442.tex", "CHARA/\u041f\u0420\u0418\u0412\u0415\u0422.TEX"),
+                         ("chara/\U00010428.tex", "CHARA/\U00010400.TEX"), ("chara/\u1f80.tex", "CHARA/\u1f88.TEX")):
+        assert kept in keys and absent not in keys
+        assert info["FileReplacements"][kept] == hashlib.sha1(blobs[6]).hexdigest().upper()
+    assert "chara/stra\u00dfe.tex" in keys and "CHARA/STRASSE.TEX" in keys
+    assert "chara/\u0131.tex" in keys and "CHARA/I.TEX" in keys
     assert len(json.load(open(ours / "glamourer_history.json"))["Entries"]) == 2
     assert len(json.load(open(ours / "customize_history.json"))["Entries"]) == 2
     # an existing <HASH>.dat is left alone, and a damaged snapshot.json stops the update

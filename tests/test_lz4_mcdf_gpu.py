@@ -414,7 +414,13 @@ def test_mcdf_import_overlapped_path(snappy, oracle, monkeypatch):
     plain = snappy.mcdf_decode_and_hash_batch(streams)
     check(plain, streams)
     monkeypatch.setenv("SNAPPY_OVERLAP_MIN_BYTES", "0")
-    for _ in range(2):
+    for waiting_kernel in ("1", "1", None):
+        # With archives this small the library itself would send everything, decode it in one
+        # launch and hash afterwards (the third turn); the first two force the waiting kernel.
+        if waiting_kernel:
+            monkeypatch.setenv("SNAPPY_MCDF_FORCE_OVERLAP", waiting_kernel)
+        else:
+            monkeypatch.delenv("SNAPPY_MCDF_FORCE_OVERLAP")
         over = snappy.mcdf_decode_and_hash_batch(streams)
         check(over, streams)
         for a, b in zip(plain, over):

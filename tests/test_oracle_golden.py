@@ -144,3 +144,24 @@ def test_mcdf_header_and_slicing(oracle):
         with pytest.raises(o.McdfError) as e:
             o.mcdf_parse_header(bad)
         assert e.value.code == code
+
+
+def test_key_folding_table_matches_the_oracle():
+    """The library folds snapshot keys (StringComparer.OrdinalIgnoreCase) with a generated table
+    (snappy_amd/csrc/unicode_upper_table.hpp); the oracle folds with simple_upper() at run time.
+    Every code point must agree, so the table cannot go stale against its generator."""
+    import os
+    import re
+
+    from oracle import oracle
+
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(here, "snappy_amd", "csrc", "unicode_upper_table.hpp")).read()
+    table = {int(a, 16): int(b, 16) for a, b in re.findall(r"\{0x([0-9A-F]+), 0x([0-9A-F]+)\}", text)}
+    assert len(table) > 1000 and sorted(table) == list(table)
+    for cp in range(0x80, 0x110000):
+        if 0xD800 <= cp <= 0xDFFF:
+            continue
+        want = ord(oracle.simple_upper(chr(cp)))
+        assert table.get(cp, cp) == want, hex(cp)
+    assert oracle._ordinal_upper("chara/é/straße/\U00010428/ı") == "CHARA/É/STRAßE/\U00010400/ı"
