@@ -977,6 +977,7 @@ def main():
             "bytes_per_gpu": [int(r[0]) for r in per_rank],
             "largest_file_bytes_per_gpu": [int(r[3]) for r in per_rank],
             "kernel_ms_per_gpu": [r[2] for r in per_rank],
+            "kernel_ms_each_step_rank0": [round(float(x), 3) for x in kernel_ms],
             "parallelism": (f"one corpus dealt out by file over {world} GPU(s), longest first by padded blocks "
                             "(snappy_plan_shards_lpt)" if strong or world == 1 else
                             f"a corpus of its own on each of {world} GPUs") + "; host dispatch, no collective",

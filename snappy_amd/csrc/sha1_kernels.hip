@@ -325,11 +325,23 @@ __device__ __forceinline__ HopResult lanes_once(const uint8_t *__restrict__ base
 // by size, so this hands out wave-sized pieces of work longest first across all
 // paths, which keeps the batch's finishing time close to max(longest chain,
 // total SIMD time / SIMDs).
+//
+// kAlone: the launch is one wave per SIMD and a chain must have its SIMD to itself
+// (a second wave on a SIMD halves the speed of the first).  The dispatcher does not
+// promise that: of 1024 single-wave workgroups on 1024 SIMDs it now and then puts
+// two on one SIMD and leaves another empty, and a batch bound by its largest file's
+// chain then takes twice as long (seen in one launch out of 6 to 20).  So this form
+// also reserves 16 accumulation registers it never touches, which brings a wave to
+// 264 of a SIMD's 512 registers: two of them cannot share a SIMD, and the 248
+// that remain still hold two decoder waves or a copy kernel's.
+template <bool kAlone>
 __global__ void __launch_bounds__(kWave)
 sha1_hop_kernel(const uint8_t *__restrict__ base, const Sha1Task *__restrict__ tasks,
                 Sha1PlanState *__restrict__ state, uint8_t *__restrict__ digests,
                 Sha1Arrival *arrival, uint32_t per_simd_round)
 {
+    if constexpr (kAlone)
+        asm volatile("" ::: "a15");
     const uint32_t lane = lane_id();
     if (blockIdx.x >= per_simd_round * __builtin_amdgcn_readfirstlane(state->waves_per_simd))
         return;
@@ -392,8 +404,12 @@ hipError_t launch_sha1_hop(const uint8_t *d_base, const Sha1Task *d_tasks, Sha1P
     // `per` workgroups make one wave per SIMD; the planner's waves_per_simd decides
     // how many of the launched rounds stay.
     const uint32_t per = n < n_simd ? n : n_simd;
-    hipLaunchKernelGGL(sha1_hop_kernel, dim3(per * static_cast<uint32_t>(waves_per_simd)),
-                       dim3(kWave), 0, stream, d_base, d_tasks, d_state, d_digests, d_arrival, per);
+    if (waves_per_simd <= 1)
+        hipLaunchKernelGGL(sha1_hop_kernel<true>, dim3(per), dim3(kWave), 0, stream, d_base, d_tasks, d_state,
+                           d_digests, d_arrival, per);
+    else
+        hipLaunchKernelGGL(sha1_hop_kernel<false>, dim3(per * static_cast<uint32_t>(waves_per_simd)),
+                           dim3(kWave), 0, stream, d_base, d_tasks, d_state, d_digests, d_arrival, per);
     return hipGetLastError();
 }
 
