@@ -28,9 +28,9 @@ def counters(summary_path):
             continue
         if section is None:
             continue
-        parts = line.split()
-        if len(parts) == 5 and parts[1] in ("FETCH_SIZE", "WRITE_SIZE"):
-            found[(section[0], parts[0], parts[1])] = float(parts[4])
+        m = re.match(r"(?:void )?(\w+)(?:<[^>]*>)?\s+(FETCH_SIZE|WRITE_SIZE)\s+\d+\s+\d+\s+([\d.]+)\s*$", line)
+        if m:   # kernel (template arguments dropped), counter, sum, dispatches, per dispatch
+            found[(section[0], m.group(1), m.group(2))] = float(m.group(3))
     return found
 
 

@@ -20,12 +20,38 @@
 //   mode 3: message schedule staged in LDS: every lane expands W[0..79] + K of its
 //           block into LDS (80 dwords per lane, 20 KiB per wave), the 80 rounds read
 //           one word each (the classic "schedule in shared memory" form)
+//   `ubench_sha1 c`: the serial chain of one message on ONE wave, schedule words (K added) already in
+//           registers, i.e. what the 64-lanes-per-file path pays per block.  A wave issues one
+//           instruction per ~4 clocks whatever it is, so a chain's time is its number of issue slots:
+//           the modes count them (the kernel's ISA is checked with -save-temps) and time them.
+//   mode 20: the product's round: v_alignbit (rotl 5), v_bitop3 (f), v_add3 (f + e + wk), v_add,
+//            v_alignbit (rotl 30): 5 slots per round.
+//   mode 21: a pair of lanes per chain.  Lane A (bank 0 of a row) only rotates the newest word by 5,
+//            lane B (bank 1) keeps the state: one v_alignbit does rotl 5 in A and rotl 30 in B (per-lane
+//            shift), v_bitop3 and v_add3 work in B, a DPP add gives A the new word and a bank-masked DPP
+//            move hands it to B: 5 slots per round again, because every v_alignbit / v_bitop3 / v_add3
+//            (VOP3: no DPP operand, writes all lanes) needs its inputs in its own lane, so the new word
+//            must travel A -> B and the sum B -> A every round, and only one of the two rides on the add.
+//            Verified against mode 20 (same digest words).
+//            The compiler also puts two wait states between the v_alignbit and the DPP add that reads its
+//            result as the plain (not the DPP) operand, which makes 6.
+//   mode 24: mode 21 with that add written in assembly, no wait states in front of it (the two a DPP
+//            operand needs after its register was written are filled by the next round's f and sum):
+//            5 slots.  If its digest words equal mode 20's, the hardware needs no wait for the plain operand.
+//   mode 22: mode 24 without the move to B: 4 slots per round, WRONG digests; it only shows what a
+//            4-slot round would run at if the hand-over were free.
+//   mode 25: mode 22 with the next round's f and sum placed between the rotate and the DPP add (also WRONG
+//            digests): does a 4-slot round run in 4 slots once nothing reads a register in the slot after
+//            its write?
+//   mode 23: rotl 5 as (a << 5) + (a >> 27) folded into the sums (v_lshrrev, v_bitop3, v_add3, v_add,
+//            v_lshl_add, v_alignbit): 6 slots, a shorter dependent path per round does not pay.
 // Reports GB/s of message bytes, wave-instructions per second and the shader
 // clock implied by s_memtime.  Build:
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I snappy_amd/csrc tools/ubench_sha1.hip -o tools/ubench_sha1
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
+#include <cstring>
 #include <vector>
 
 #include "sha1_device.hpp"
@@ -250,6 +276,143 @@ bench(const uint8_t *base, uint64_t stride, uint32_t blocks_per_lane, uint32_t *
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// `c`: one wave, one chain (see the head of this file).
+// ---------------------------------------------------------------------------
+constexpr int kRowShr4 = 0x114, kRowShl4 = 0x104, kQuadSame = 0xE4;
+
+template <int MODE>
+__global__ void __launch_bounds__(64)
+chain(uint32_t blocks, uint32_t seed, uint32_t *out, uint64_t *clk)
+{
+    const uint32_t lane = threadIdx.x;
+    const bool is_a = ((lane >> 2) & 1u) == 0;   // banks 0 and 2 of each row: the lanes that only rotate by 5
+    const uint32_t sh = (MODE == 21 || MODE == 22 || MODE == 24 || MODE == 25) ? (is_a ? 27u : 2u) : 27u;
+    uint32_t wk[80];
+#pragma unroll
+    for (int t = 0; t < 80; ++t) {
+        wk[t] = (uint32_t(t) * 2654435761u + 12345u) ^ (seed * 40503u);
+        asm volatile("" : "+v"(wk[t]));
+    }
+    uint32_t h[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k)
+        h[k] = kSha1Init[k];
+    const uint64_t t0 = __builtin_amdgcn_s_memtime();
+    for (uint32_t blk = 0; blk < blocks; ++blk) {
+        uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4];
+        if (MODE == 20) {
+#pragma unroll
+            for (int t = 0; t < 80; ++t)
+                sha1_round<true>(t, a, b, c, d, e, wk[t]);
+        } else if (MODE == 21 || MODE == 22 || MODE == 24 || MODE == 25) {
+            // x: the newest word a, in lane A and (after the move) in lane B = A + 4, which keeps
+            // b, c, d, e.  B's rotl30 of a becomes c two rounds later.
+            uint32_t x = a;
+            uint32_t rot_b = rotl32(b, 30);
+            uint32_t s = sha1_f(0, b, c, d) + e + wk[0];                 // B: f + e + wk of the round to come
+            asm volatile("" : "+v"(s));
+#pragma unroll
+            for (int t = 0; t < 80; ++t) {
+                const uint32_t y = __builtin_amdgcn_alignbit(x, x, sh);  // A: rotl5(a)   B: rotl30(a)
+                uint32_t s_next = 0;
+                if (MODE == 25 && t < 79) {   // the next round's f and sum between the rotate and the add
+                    __builtin_amdgcn_sched_barrier(0);
+                    s_next = sha1_f(t + 1, x, rot_b, c) + d + wk[t + 1];
+                    asm volatile("" : "+v"(s_next));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                // A: the new word = s of lane + 4 (DPP operand of the add) + y
+                uint32_t nx;
+                if (MODE == 21)
+                    nx = __builtin_amdgcn_update_dpp(0u, s, kRowShl4, 0xF, 0xF, true) + y;
+                else  // the same add written out, so that the compiler cannot put wait states in front of it
+                    asm volatile("v_add_u32_dpp %0, %1, %2 row_shl:4 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+                                 : "=v"(nx) : "v"(s), "v"(y));
+                e = d;
+                d = c;
+                c = rot_b;
+                rot_b = y;
+                b = x;
+                // The next round's f + e + wk needs nothing of this round's result: it fills the two
+                // wait states a DPP read needs after the write of its source.
+                if (MODE == 25) {
+                    s = s_next;
+                } else if (t < 79) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    s = sha1_f(t + 1, b, c, d) + e + wk[t + 1];
+                    asm volatile("" : "+v"(s));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (MODE != 22 && MODE != 25)   // B (banks 1 and 3) takes the new word from lane - 4
+                    nx = __builtin_amdgcn_update_dpp(nx, nx, kRowShr4, 0xF, 0xA, false);
+                x = nx;
+            }
+            a = x;
+        } else {  // MODE 23
+#pragma unroll
+            for (int t = 0; t < 80; ++t) {
+                uint32_t g = sha1_f(t, b, c, d) + e + wk[t];
+                asm volatile("" : "+v"(g));
+                uint32_t g2 = g + (a >> 27);
+                asm volatile("" : "+v"(g2));
+                const uint32_t tmp = (a << 5) + g2;
+                e = d;
+                d = c;
+                c = rotl32(b, 30);
+                b = a;
+                a = tmp;
+            }
+        }
+        // The hop of the product's kernel (five DPP moves), here onto the same lane.
+        h[0] = __builtin_amdgcn_update_dpp(0u, h[0] + a, kQuadSame, 0xF, 0xF, false);
+        h[1] = __builtin_amdgcn_update_dpp(0u, h[1] + b, kQuadSame, 0xF, 0xF, false);
+        h[2] = __builtin_amdgcn_update_dpp(0u, h[2] + c, kQuadSame, 0xF, 0xF, false);
+        h[3] = __builtin_amdgcn_update_dpp(0u, h[3] + d, kQuadSame, 0xF, 0xF, false);
+        h[4] = __builtin_amdgcn_update_dpp(0u, h[4] + e, kQuadSame, 0xF, 0xF, false);
+    }
+    const uint64_t t1 = __builtin_amdgcn_s_memtime();
+#pragma unroll
+    for (int k = 0; k < 5; ++k)
+        out[lane * 5 + k] = h[k];
+    if (lane == 0)
+        clk[0] = t1 - t0;
+}
+
+template <int MODE>
+static void run_chain(uint32_t blocks, const uint32_t *expect, uint32_t *keep)
+{
+    uint32_t *d_out;
+    uint64_t *d_clk;
+    (void)hipMalloc(&d_out, 64 * 5 * 4);
+    (void)hipMalloc(&d_clk, 8);
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    hipLaunchKernelGGL(chain<MODE>, dim3(1), dim3(64), 0, 0, blocks, 7u, d_out, d_clk);
+    (void)hipEventRecord(e0, 0);
+    hipLaunchKernelGGL(chain<MODE>, dim3(1), dim3(64), 0, 0, blocks, 7u, d_out, d_clk);
+    (void)hipEventRecord(e1, 0);
+    (void)hipEventSynchronize(e1);
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    uint32_t got[64 * 5];
+    uint64_t ticks = 0;
+    (void)hipMemcpy(got, d_out, sizeof got, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(&ticks, d_clk, 8, hipMemcpyDeviceToHost);
+    const uint32_t *mine = got + 4 * 5;   // lane 4: a state-keeping lane in every mode
+    const char *verdict = "reference";
+    if (expect)
+        verdict = (memcmp(mine, expect, 20) == 0) ? "digest words equal mode 20's" : "DIGEST WORDS DIFFER from mode 20's";
+    if (keep)
+        memcpy(keep, mine, 20);
+    printf("chain mode %d  %u blocks  %.3f ms  %.1f ns/block  %.1f memtime ticks/block  state %08x %08x ...  %s\n", MODE,
+           blocks, ms, ms * 1e6 / blocks, double(ticks) / blocks, mine[0], mine[1], verdict);
+    (void)hipFree(d_out);
+    (void)hipFree(d_clk);
+}
+
 // Data that differs from place to place, so that a mode that delivers the wrong bytes shows in the check word.
 __global__ void fill(uint32_t *d, size_t n)
 {
@@ -294,6 +457,18 @@ static void run(int blocks_per_cu, uint32_t blocks_per_lane, const uint8_t *d_da
 
 int main(int argc, char **argv)
 {
+    if (argc > 1 && argv[1][0] == 'c') {
+        uint32_t ref[5];
+        for (int rep = 0; rep < 2; ++rep) {
+            run_chain<20>(100000, nullptr, ref);
+            run_chain<21>(100000, ref, nullptr);
+            run_chain<22>(100000, ref, nullptr);
+            run_chain<23>(100000, ref, nullptr);
+            run_chain<24>(100000, ref, nullptr);
+            run_chain<25>(100000, ref, nullptr);
+        }
+        return 0;
+    }
     if (argc > 1 && argv[1][0] == 's') {
         // Sustained load: the register-only mode back to back for about half a second, to see
         // whether the clock (and with it the ceiling) holds beyond a few milliseconds.
