@@ -548,6 +548,84 @@ def extra_sha1_workload(name, lib, native, torch, device, local_rank, n_cu, want
     return res
 
 
+def concurrent_callers(lib, native, torch, device, local_rank):
+    """Two callers at once on one GPU, as the reference can have them: the migration task hashing
+    on a pool thread (Snappy/Plugin.cs:257-278, Data/SnapshotMigrator.cs:62-86) while the UI thread
+    saves a snapshot (Core/SnapshotManager.cs:312-324).  Each caller is a thread with a batch of
+    its own in HBM; the wall time of both against the time of each alone."""
+    import threading
+
+    def corpus(name, seed):
+        lengths = make_sizes(name, np.random.default_rng(CORPUS_SEED), 1.0)
+        offsets = np.concatenate([[0], np.cumsum(lengths)[:-1]]).astype(np.uint64)
+        buf = fill_random(torch, int(lengths.sum()), device, seed=seed)
+        return {"name": name, "lengths": lengths, "offsets": offsets, "buf": buf, "bytes": int(lengths.sum()),
+                "digests": np.zeros((len(lengths), 20), dtype=np.uint8)}
+
+    def call(c):
+        native.check(lib.snappy_sha1_batch_device(local_rank, c["buf"].data_ptr(), c["offsets"].ctypes.data,
+                                                  c["lengths"].ctypes.data, len(c["lengths"]),
+                                                  c["digests"].ctypes.data, None), "snappy_sha1_batch_device")
+
+    def alone(c, reps=3):
+        call(c)
+        t = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            call(c)
+            t.append(time.perf_counter() - t0)
+        return min(t)
+
+    def together(cs, reps=3):
+        best = None
+        for _ in range(reps):
+            gate = threading.Barrier(len(cs) + 1)
+            lat = [0.0] * len(cs)
+
+            def work(i):
+                gate.wait()
+                t0 = time.perf_counter()
+                call(cs[i])
+                lat[i] = time.perf_counter() - t0
+
+            threads = [threading.Thread(target=work, args=(i,)) for i in range(len(cs))]
+            for th in threads:
+                th.start()
+            gate.wait()
+            t0 = time.perf_counter()
+            for th in threads:
+                th.join()
+            wall = time.perf_counter() - t0
+            if best is None or wall < best[0]:
+                best = (wall, list(lat))
+        return best
+
+    res = {"what": "two threads, one snappy_sha1_batch_device call each at the same moment on one GPU, batches resident "
+                   "in HBM; wall time of the pair against each call alone (best of 3)"}
+    f1, f2 = corpus("folder", 501), corpus("folder", 502)
+    t1 = alone(f1)
+    wall, lat = together([f1, f2])
+    keep = f1["digests"].copy()
+    call(f1)
+    res["folder_and_folder"] = {
+        "alone_ms": t1 * 1e3, "alone_GBps": f1["bytes"] / t1 / GB, "pair_wall_ms": wall * 1e3,
+        "pair_latency_ms": [x * 1e3 for x in lat], "aggregate_GBps": (f1["bytes"] + f2["bytes"]) / wall / GB,
+        "aggregate_over_alone": (f1["bytes"] + f2["bytes"]) / wall / (f1["bytes"] / t1),
+        "digests_same_as_alone": bool(np.array_equal(keep, f1["digests"]))}
+    del f2
+    sm = corpus("small", 503)
+    ts = alone(sm)
+    wall, lat = together([f1, sm])
+    res["folder_and_small_files"] = {
+        "folder_alone_ms": t1 * 1e3, "small_files_alone_ms": ts * 1e3, "pair_wall_ms": wall * 1e3,
+        "pair_latency_ms": {"folder": lat[0] * 1e3, "small_files": lat[1] * 1e3},
+        "aggregate_GBps": (f1["bytes"] + sm["bytes"]) / wall / GB,
+        "one_after_the_other_ms": (t1 + ts) * 1e3}
+    del f1, sm
+    torch.cuda.empty_cache()
+    return res
+
+
 def extra_workloads(args, lib, native, torch, device, local_rank, n_cu):
     """The other single-GPU configurations, measured briefly after the headline run so that one
     bench line carries every configuration and every kernel's roofline."""
@@ -555,6 +633,7 @@ def extra_workloads(args, lib, native, torch, device, local_rank, n_cu):
     res["blobs"] = extra_sha1_workload("blobs", lib, native, torch, device, local_rank, n_cu, True)
     res["small_files"] = extra_sha1_workload("small", lib, native, torch, device, local_rank, n_cu, True)
     res["folder"] = extra_sha1_workload("folder", lib, native, torch, device, local_rank, n_cu, True)
+    res["concurrent_callers"] = concurrent_callers(lib, native, torch, device, local_rank)
 
     # MCDF import: lz4net decode + slice + hash, 8 archives of 256 MiB in one call, on both kinds of
     # content: long runs (random, zeros, repeated motifs) and dense short sequences (what an LZ4
@@ -830,6 +909,8 @@ def main():
                     help="no GPU: exercise the multi-rank plumbing with hashlib standing in for the "
                          "kernels on a tiny corpus (used by the gloo test; the numbers mean nothing)")
     ap.add_argument("--cpu-sample-gb", type=float, default=4.0)
+    ap.add_argument("--only-concurrent", action="store_true",
+                    help="measure only the two-callers-at-once case (other_workloads.concurrent_callers) and print it")
     ap.add_argument("--no-extra", action="store_true",
                     help="skip the brief measurements of the other configurations appended to the default run")
     ap.add_argument("--e2e-max-gb", type=float, default=120.0,
@@ -882,6 +963,10 @@ def main():
         if dist is not None:
             dist.barrier()
             dist.destroy_process_group()
+
+    if args.only_concurrent:
+        print(json.dumps({"concurrent_callers": concurrent_callers(lib, native, torch, device, local_rank)}), flush=True)
+        return finish()
 
     if args.workload == "mcdf":
         out = run_mcdf(args, rank, world, local_rank, dist)
