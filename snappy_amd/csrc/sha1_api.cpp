@@ -24,31 +24,37 @@ namespace {
 
 // Cost model, used only to cut a batch into the kernel's paths (groups of 64 / 16
 // / 4 / 1 lanes per message).  chain: nanoseconds a message spends per 64-byte
-// block when its wavefront has a SIMD to itself (one instruction issues per ~4.2
+// block when its wavefront has a SIMD to itself (one instruction issues per ~4.1
 // cycles; 412 instructions per block on the chain plus the schedule expansion
-// shared by the group).  simd: SIMD time a block costs.
+// shared by the group).  The SIMD time a block costs is the chain time divided by
+// the messages a wave carries.
 //
-// The table is what one MI355X gave with the chip busy on each path.  Its ratios
-// follow from the paths' instruction counts and from how much the clock gives way
-// under each kind of load, and the cut is sensitive to them (with chain times
-// measured on an idle chip, 709 / 768 / 900 / 1190 ns, the mixed corpus took 302 ms
-// instead of 266: the largest files moved from 64 to 16 lanes each).  What differs
-// from box to box is the level, so that is what is measured: the 64-lane chain, one
-// message alone on the GPU at two sizes, the first time a device hashes (about 7 ms
-// once per device and process), and the whole table is scaled by what comes out
-// against kIdleChainNs.  SNAPPY_SHA1_CALIBRATE=0 switches the measurement off; a
+// The table is what one MI355X gave with the other SIMDs busy (tools/probe_planner.py,
+// tools/probe_one_lane_chain.py; alone on the chip the chains run at 705 / 775 / 900 /
+// 1190 ns).  What differs from box to box is the level, so that is what is measured: the
+// 64-lane chain, one message alone on the GPU at two sizes, the first time a device hashes
+// (about 7 ms once per device and process), and the whole table is scaled by what comes
+// out against kIdleChainNs.  SNAPPY_SHA1_CALIBRATE=0 switches the measurement off; a
 // result outside 0.6-1.6 times the expected one (a busy GPU) is not used.
-constexpr double kChainNs[kSha1Paths] = {723.0, 799.0, 985.0, 3000.0};
-constexpr double kSimdNs[kSha1Paths] = {723.0, 199.7, 61.6, 26.0};
+constexpr double kChainNs[kSha1Paths] = {716.0, 795.0, 960.0, 1300.0};
 constexpr double kIdleChainNs = 709.0;  // the 64-lane chain on the same MI355X with nothing else running
-// The one-lane chain runs at 1300-1670 ns per block when the whole chip does
-// one-lane work, but next to wide-group waves on a mixed corpus files of 6-10 MB
-// were seen at up to ~2800 ns per block, and their waves then decided the
-// finishing time (270-440 ms per step instead of a steady 262 ms): the planner
-// is told the pessimistic figure, which sends such files to the 4-lane path.
+// The one-lane path streams 64 files per wave, 64 bytes per lane and block.  With a wave's
+// files next to each other in memory its chain runs at 1190-1300 ns per block whatever the
+// file size; with the files of a wave scattered over the batch (the planner orders by size,
+// not by address) it ran at 1490 ns per block over 28 GB, 1880 over 112 GB and 2070 over
+// 140 GB, unsteadily (tools/probe_one_lane_big.py), and at up to 2800 next to wide-group
+// waves on a 100 GB corpus, where such waves then decided the finishing time.  So the chain
+// is priced by the batch's address span, up to a cap that sends multi-megabyte files of a
+// large corpus to the 4-lane path (900-915 ns per block wherever its files lie).
+constexpr double kOneLaneNsPerGb = 17.0;
+constexpr double kOneLaneCapNs = 3000.0;
+constexpr double kOneLaneOrderNs = 1800.0;
 
-// How much slower chains run when all SIMDs are busy (the clock drops under load).
-constexpr double kLoadSlowdown = 0.45;
+// Chains measured next to a chip full of other work are 1-3 % slower than in the table's
+// conditions; no further allowance is made (a factor of up to 1.45 was used before the
+// launches were made one wave per SIMD for certain: it had absorbed the launches in
+// which two waves shared a SIMD).
+constexpr double kLoadSlowdown = 0.0;
 
 long env_long(const char *name, long fallback)
 {
@@ -63,13 +69,24 @@ Sha1CostModel sha1_cost_model(const DeviceCtx &dev, bool waits_for_transfer)
     const uint32_t n_simd = 4u * static_cast<uint32_t>(dev.n_cu);
     Sha1CostModel model;
     const double level = dev.cost_measured.load(std::memory_order_acquire) ? dev.chain_level : 1.0;
-    for (int k = 0; k < kSha1Paths; ++k) {
+    for (int k = 0; k < kSha1Paths; ++k)
         model.chain_ns[k] = kChainNs[k] * level;
-        model.simd_ns[k] = kSimdNs[k] * level;
+    model.one_lane_ns_per_gb = kOneLaneNsPerGb * level;
+    model.one_lane_cap_ns = kOneLaneCapNs * level;
+    // For the hand-out order the one-lane chain counts with what it usually takes, not with the cap.
+    model.one_lane_order_ns =
+        static_cast<double>(env_long("SNAPPY_SHA1_ONE_LANE_ORDER_NS", static_cast<long>(kOneLaneOrderNs))) * level;
+    if (const char *v = std::getenv("SNAPPY_SHA1_CHAIN_NS")) {  // tuning: "c0,c1,c2,c3[,per GB,cap]"
+        const int got = std::sscanf(v, "%lf,%lf,%lf,%lf,%lf,%lf", &model.chain_ns[0], &model.chain_ns[1],
+                                    &model.chain_ns[2], &model.chain_ns[3], &model.one_lane_ns_per_gb,
+                                    &model.one_lane_cap_ns);
+        if (got < 6) {  // a fixed one-lane figure
+            model.one_lane_ns_per_gb = 0.0;
+            model.one_lane_cap_ns = model.chain_ns[3];
+        }
     }
-    if (const char *v = std::getenv("SNAPPY_SHA1_CHAIN_NS"))  // tuning: "c0,c1,c2,c3"
-        std::sscanf(v, "%lf,%lf,%lf,%lf", &model.chain_ns[0], &model.chain_ns[1], &model.chain_ns[2],
-                    &model.chain_ns[3]);
+    for (int k = 0; k < kSha1Paths; ++k)
+        model.simd_ns[k] = model.chain_ns[k] * kHopGroupLanes[k] / 64.0;
     model.n_simd = n_simd;
     model.load_slowdown = kLoadSlowdown;
     if (const char *v = std::getenv("SNAPPY_SHA1_LOAD_SLOWDOWN"))  // tuning
@@ -129,6 +146,7 @@ void measure_chain_times(SlotLease &lease)
     Sha1CostModel model = {};
     for (int k = 0; k < kSha1Paths; ++k)
         model.chain_ns[k] = model.simd_ns[k] = kChainNs[k];
+    model.one_lane_cap_ns = kChainNs[kSha1Paths - 1];
     model.n_simd = n_simd;
     model.forced_waves = 1;
     double measured = 0.0;

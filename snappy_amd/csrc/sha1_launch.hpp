@@ -25,6 +25,15 @@ constexpr int kHopGroupLanes[kSha1Paths] = {64, 16, 4, 1};
 struct Sha1CostModel {
     double chain_ns[kSha1Paths];
     double simd_ns[kSha1Paths];
+    // The one-lane chain depends on how far apart in memory the 64 files of a wave lie: a batch
+    // spread over `span` bytes is priced at min(chain_ns[3] + one_lane_ns_per_gb * span / 2^30,
+    // one_lane_cap_ns); simd_ns[3] follows (1/64 of it).
+    double one_lane_ns_per_gb;
+    double one_lane_cap_ns;
+    // The kernel hands work out longest first by blocks x chain time.  For that ORDER the one-lane
+    // chain counts with at most this figure: priced for the worst case it would put one-lane pieces
+    // ahead of wide-group pieces that really run longer, and those would then start late.
+    double one_lane_order_ns;
     double load_slowdown;     // chains run up to (1 + this) times slower when every SIMD is busy
     uint32_t n_simd;
     int forced_path;          // >= 0: everything takes this path (testing / tuning)
@@ -40,7 +49,12 @@ struct Sha1PlanState {
     double planned_ns;                // the model's finishing time for the chosen cut
     float chain_ns[kSha1Paths];       // the model's chain times, for the kernel's work order
     uint32_t waves_per_simd;          // 1: chains decide the finishing time; 2: bulk throughput
-    uint32_t reserved1[16];
+    uint32_t reserved0;
+    // Address range of the batch: the largest ~offset (i.e. the smallest offset, kept this way so
+    // that the zeroed header is the neutral start) and the largest end.
+    unsigned long long span_lo_inverted;
+    unsigned long long span_hi;
+    uint32_t reserved1[11];
     struct alignas(128) Queue {       // next task of a path, counted from its range's start
         uint32_t next;
     } queue[kSha1Paths];

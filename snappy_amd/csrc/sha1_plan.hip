@@ -39,11 +39,12 @@ __device__ __forceinline__ double bucket_floor(uint32_t b)
 // Pass 1: histogram of buckets (reversed so that big buckets come first), total
 // and largest block count.
 __global__ void __launch_bounds__(kPlanThreads)
-plan_histogram(const uint64_t *__restrict__ lengths, uint32_t n, Sha1PlanState *__restrict__ st)
+plan_histogram(const uint64_t *__restrict__ offsets, const uint64_t *__restrict__ lengths, uint32_t n,
+               Sha1PlanState *__restrict__ st)
 {
     __shared__ uint32_t hist[kPlanBuckets];
     __shared__ unsigned long long sums[kPlanBuckets];
-    __shared__ unsigned long long s_total, s_max;
+    __shared__ unsigned long long s_total, s_max, s_lo_inv, s_hi;
     for (int k = threadIdx.x; k < kPlanBuckets; k += kPlanThreads) {
         hist[k] = 0;
         sums[k] = 0;
@@ -51,17 +52,25 @@ plan_histogram(const uint64_t *__restrict__ lengths, uint32_t n, Sha1PlanState *
     if (threadIdx.x == 0) {
         s_total = 0;
         s_max = 0;
+        s_lo_inv = 0;
+        s_hi = 0;
     }
     __syncthreads();
-    unsigned long long total = 0, mx = 0;
+    unsigned long long total = 0, mx = 0, lo_inv = 0, hi = 0;
     const uint32_t base = blockIdx.x * (kPlanThreads * kFilesPerThread);
 #pragma unroll
     for (int j = 0; j < kFilesPerThread; ++j) {
         const uint32_t i = base + j * kPlanThreads + threadIdx.x;
         if (i < n) {
-            const uint64_t b = padded_blocks(lengths[i]);
+            const uint64_t len = lengths[i];
+            const uint64_t b = padded_blocks(len);
             total += b;
             mx = b > mx ? b : mx;
+            if (len) {
+                const uint64_t off = offsets[i];
+                lo_inv = ~off > lo_inv ? ~off : lo_inv;
+                hi = off + len > hi ? off + len : hi;
+            }
             const uint32_t pos = kPlanBuckets - 1 - size_bucket(b);
             atomicAdd(&hist[pos], 1u);
             atomicAdd(&sums[pos], static_cast<unsigned long long>(b));
@@ -69,6 +78,8 @@ plan_histogram(const uint64_t *__restrict__ lengths, uint32_t n, Sha1PlanState *
     }
     atomicAdd(&s_total, total);
     atomicMax(&s_max, mx);
+    atomicMax(&s_lo_inv, lo_inv);
+    atomicMax(&s_hi, hi);
     __syncthreads();
     for (int k = threadIdx.x; k < kPlanBuckets; k += kPlanThreads)
         if (hist[k]) {
@@ -78,6 +89,8 @@ plan_histogram(const uint64_t *__restrict__ lengths, uint32_t n, Sha1PlanState *
     if (threadIdx.x == 0) {
         atomicAdd(&st->total_blocks, s_total);
         atomicMax(&st->max_blocks, s_max);
+        atomicMax(&st->span_lo_inverted, s_lo_inv);
+        atomicMax(&st->span_hi, s_hi);
     }
 }
 
@@ -134,8 +147,17 @@ plan_scan(Sha1PlanState *__restrict__ st, uint32_t n, Sha1CostModel m)
     __shared__ float dur[kPlanWaves][kPlanBuckets];
     __shared__ uint32_t pieces[kPlanWaves][kPlanBuckets];
     __shared__ double cand_bound[kPlanCandidates], cand_d[kPlanCandidates];
+    __shared__ double cand_longest[kPlanCandidates], cand_load[kPlanCandidates], cand_late[kPlanCandidates];
     __shared__ uint32_t n_used;
-    __shared__ double best_bound, best_d;
+    __shared__ double best_bound, best_d, best_longest, best_load, best_late;
+    // The one-lane chain as this batch's spread in memory prices it (every thread computes the same).
+    {
+        const unsigned long long lo = ~st->span_lo_inverted, hi = st->span_hi;
+        const double span_gb = hi > lo ? static_cast<double>(hi - lo) / 1073741824.0 : 0.0;
+        m.chain_ns[kSha1Paths - 1] = fmin(m.chain_ns[kSha1Paths - 1] + m.one_lane_ns_per_gb * span_gb,
+                                          fmax(m.one_lane_cap_ns, m.chain_ns[kSha1Paths - 1]));
+        m.simd_ns[kSha1Paths - 1] = m.chain_ns[kSha1Paths - 1] / 64.0;
+    }
     const uint32_t k = threadIdx.x;
     const uint32_t lane = k & 63u, wave = k >> 6;
     const uint32_t count = st->hist[k];
@@ -227,6 +249,9 @@ plan_scan(Sha1PlanState *__restrict__ st, uint32_t n, Sha1CostModel m)
                     const double slow = 1.0 + m.load_slowdown * fmin(1.0, load / first);
                     cand_bound[c] = fmax(static_cast<double>(longest) * slow, load + static_cast<double>(late) * slow);
                     cand_d[c] = d_max;
+                    cand_longest[c] = static_cast<double>(longest) * slow;
+                    cand_load[c] = load;
+                    cand_late[c] = static_cast<double>(late) * slow;
                 }
                 __syncthreads();
             }
@@ -235,6 +260,9 @@ plan_scan(Sha1PlanState *__restrict__ st, uint32_t n, Sha1CostModel m)
                     if (best_bound < 0.0 || cand_bound[c] < 0.98 * best_bound) {  // move on only for a clear gain
                         best_bound = cand_bound[c];
                         best_d = cand_d[c];
+                        best_longest = cand_longest[c];
+                        best_load = cand_load[c];
+                        best_late = cand_late[c];
                     }
             }
             __syncthreads();
@@ -277,10 +305,17 @@ plan_scan(Sha1PlanState *__restrict__ st, uint32_t n, Sha1CostModel m)
         st->path_end[q] = cut[q];
     for (int q = 0; q < kSha1Paths; ++q)
         st->chain_ns[q] = static_cast<float>(m.chain_ns[q]);
+    if (m.one_lane_order_ns > 0.0)
+        st->chain_ns[kSha1Paths - 1] = static_cast<float>(fmin(m.chain_ns[kSha1Paths - 1], m.one_lane_order_ns));
     if (m.forced_waves > 0)
         waves = m.forced_waves < kMaxWavesPerSimd ? m.forced_waves : kMaxWavesPerSimd;
     st->waves_per_simd = waves;
-    st->planned_ns = m.forced_path >= 0 ? 0.0 : best_bound;
+    // The cut minimises the list-scheduling BOUND max(longest, load + late).  What is reported is the
+    // expected finishing time under it: the pieces that wait for a SIMD are handed out longest first,
+    // so what sticks out over the average load at the end is on average half a late piece, and a
+    // second wave per SIMD hides a fifth of the one-lane path's SIMD time.
+    const double load = best_load * (waves == 2u ? 0.8 : 1.0);
+    st->planned_ns = m.forced_path >= 0 ? 0.0 : fmax(best_longest, load + 0.5 * best_late);
 }
 
 // Pass 3: scatter the tasks to their bucket ranges.  A workgroup counts its files
@@ -372,7 +407,7 @@ hipError_t launch_sha1_plan(const uint64_t *d_offsets, const uint64_t *d_lengths
         return e;
     const uint32_t per_group = kPlanThreads * kFilesPerThread;
     const uint32_t groups = (n + per_group - 1) / per_group;
-    hipLaunchKernelGGL(plan_histogram, dim3(groups), dim3(kPlanThreads), 0, stream, d_lengths, n,
+    hipLaunchKernelGGL(plan_histogram, dim3(groups), dim3(kPlanThreads), 0, stream, d_offsets, d_lengths, n,
                        d_state);
     hipLaunchKernelGGL(plan_scan, dim3(1), dim3(kPlanBuckets), 0, stream, d_state, n, model);
     hipLaunchKernelGGL(plan_scatter, dim3(groups), dim3(kPlanThreads), 0, stream, d_offsets,
