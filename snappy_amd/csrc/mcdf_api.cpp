@@ -6,6 +6,8 @@
 // one decode launch and one hash launch: an archive is only 64-512 chunks, too
 // few to occupy the GPU on its own.
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <thread>
@@ -234,6 +236,26 @@ int import_batch_overlapped(SlotLease &lease, std::vector<StreamJob> &jobs, std:
     if (!ordered.empty())
         SNAPPY_HIP_TRY(hipMemcpy(d_table, ordered.data(), ordered.size() * sizeof(Lz4Chunk), hipMemcpyHostToDevice));
 
+    // The files in the order their archives arrive (stable: an archive's files keep their order).
+    {
+        std::vector<size_t> by_arrival(owner.size());
+        for (size_t k = 0; k < by_arrival.size(); ++k)
+            by_arrival[k] = k;
+        std::stable_sort(by_arrival.begin(), by_arrival.end(), [&](size_t x, size_t y) {
+            return epoch_of[owner[x].first] < epoch_of[owner[y].first];
+        });
+        std::vector<uint64_t> off2(owner.size()), len2(owner.size());
+        std::vector<std::pair<size_t, size_t>> own2(owner.size());
+        for (size_t k = 0; k < by_arrival.size(); ++k) {
+            off2[k] = offsets[by_arrival[k]];
+            len2[k] = lengths[by_arrival[k]];
+            own2[k] = owner[by_arrival[k]];
+        }
+        offsets.swap(off2);
+        lengths.swap(len2);
+        owner.swap(own2);
+    }
+
     // A chunk is decoded by one wave, and on streams of short sequences its chain of
     // sequences takes milliseconds (long copies: 0.3 ms).  Next to a resident SHA-1
     // kernel only half as many decoder waves fit on a CU, so decoding such archives
@@ -252,18 +274,14 @@ int import_batch_overlapped(SlotLease &lease, std::vector<StreamJob> &jobs, std:
         first_chunks_ms * (mean_chunk > kHeaderPrefix ? static_cast<float>(mean_chunk) / kHeaderPrefix : 1.f);
     // (Decodes run on a stream of their own, beside the following transfers, in runs of up to
     // eight archives: only a chunk that takes several archives' transfers puts them behind.)
-    // The waiting kernel hands its files out largest first over the whole batch, whatever
-    // archive they belong to: with many archives most waves soon hold a file of an archive
-    // that is still to come and sit on it while files that have arrived go unclaimed, and the
-    // import takes transfers plus hashing instead of the longer of the two.  The overlap pays
-    // when the transfers are short next to the largest file's chain (0.72 us per 64-byte
-    // block), which then runs beside nearly all of them; otherwise the plain order is as fast.
-    uint64_t largest_file = 0;
-    for (uint64_t v : lengths)
-        largest_file = std::max(largest_file, v);
-    const float chain_ms = static_cast<float>(largest_file / 64u) * 0.72e-3f;
-    const float all_transfers_ms = static_cast<float>(stream_bytes) / 50e6f;
-    const bool overlap_pays = all_transfers_ms <= 0.35f * chain_ms || std::getenv("SNAPPY_MCDF_FORCE_OVERLAP") != nullptr;
+    // The waiting kernel takes the files group by group in the order of arrival (one group per
+    // decode launch, below), largest first inside a group, so a wave never sits on a file of an
+    // archive that is still to come while files that have arrived go unclaimed.  The import then
+    // takes about the longer of "all transfers" and "the largest file's chain after its
+    // archive's transfer" instead of their sum.  SNAPPY_MCDF_PLAIN_ORDER=1: send all, decode all,
+    // hash (comparisons).
+    const bool overlap_pays = std::getenv("SNAPPY_MCDF_PLAIN_ORDER") == nullptr ||
+                              std::getenv("SNAPPY_MCDF_FORCE_OVERLAP") != nullptr;
     if (!order.empty() && (!overlap_pays || whole_chunk_ms > 4.f * static_cast<float>(mean_stream) / 50e6f)) {
         std::vector<Piece> all;
         for (size_t a = 0; a < n; ++a)  // arena order
@@ -293,6 +311,45 @@ int import_batch_overlapped(SlotLease &lease, std::vector<StreamJob> &jobs, std:
         return finish_overlapped(s, jobs, states, digests_out, order, first_row, ordered.size(), owner, hashed);
     }
 
+    // The decode launches: the first archive alone (it holds the largest file, whose SHA-1 chain
+    // decides when the import ends), the others in runs of `run_len`, larger where a chunk takes
+    // long next to an archive's transfer (a decode launch lasts as long as one chunk's chain of
+    // sequences, however few chunks it has).  run_end_at[k]: a run ends with the k-th arrival.
+    const float transfer_ms = static_cast<float>(mean_stream) / 50e6f;  // one archive at PCIe rate
+    size_t run_len = 1;
+    if (whole_chunk_ms > 0.25f * transfer_ms)
+        run_len = std::min<size_t>(8, static_cast<size_t>(4.f * whole_chunk_ms / (transfer_ms > 0.f ? transfer_ms : 1.f)) + 1);
+    if (const char *v = std::getenv("SNAPPY_MCDF_DECODE_RUN"))  // tuning
+        run_len = std::max<size_t>(1, std::strtoul(v, nullptr, 10));
+    std::vector<bool> run_end_at(order.size(), false);
+    {
+        size_t from = 0;
+        for (size_t k = 0; k < order.size(); ++k)
+            if (k == 0 || k + 1 == order.size() || k + 1 - from >= run_len) {
+                run_end_at[k] = true;
+                from = k + 1;
+            }
+    }
+    // The hashing groups: the files of one run each (of several runs once there are more than
+    // kMaxHashGroups runs; every file still waits for its own archive's number).
+    constexpr size_t kMaxHashGroups = 64;
+    std::vector<uint32_t> group_ends;
+    {
+        size_t runs = 0;
+        for (size_t k = 0; k < order.size(); ++k)
+            runs += run_end_at[k] ? 1 : 0;
+        const size_t runs_per_group = (runs + kMaxHashGroups - 1) / kMaxHashGroups;
+        size_t file = 0, seen_runs = 0;
+        for (size_t k = 0; k < order.size(); ++k) {
+            while (file < owner.size() && epoch_of[owner[file].first] <= k + 1)
+                ++file;
+            if (run_end_at[k] && (++seen_runs % std::max<size_t>(1, runs_per_group) == 0 || k + 1 == order.size() || k == 0))
+                group_ends.push_back(static_cast<uint32_t>(file));
+        }
+        if (group_ends.empty() || group_ends.back() != owner.size())
+            group_ends.push_back(static_cast<uint32_t>(owner.size()));
+    }
+
     // 3. The SHA-1 kernel, waiting.  Everything it or the transfers need is allocated first.
     const size_t n_files = owner.size();
     const size_t table_bytes = n_files * sizeof(uint64_t);
@@ -316,7 +373,8 @@ int import_batch_overlapped(SlotLease &lease, std::vector<StreamJob> &jobs, std:
     uint64_t largest_stream = 0;
     for (size_t a : order)
         largest_stream = std::max<uint64_t>(largest_stream, jobs[a].in_len);
-    if ((st = reserve_transfer_ring(s, kTransferSliceBytes, (largest_stream + kTransferSliceBytes - 1) / kTransferSliceBytes)) != SNAPPY_OK)
+    (void)largest_stream;
+    if ((st = reserve_transfer_ring(s, kTransferSliceBytes, 2 * order.size() + stream_bytes / kTransferSliceBytes + 1)) != SNAPPY_OK)
         return st;
     if (n_files) {
         // The tables, the arrival numbers and the digests share one buffer.
@@ -342,7 +400,8 @@ int import_batch_overlapped(SlotLease &lease, std::vector<StreamJob> &jobs, std:
         SNAPPY_HIP_TRY(hipMemcpyAsync(d_len, lengths.data(), table_bytes, hipMemcpyHostToDevice, s.stream));
         SNAPPY_HIP_TRY(hipMemcpyAsync(d_epochs, epochs.data(), n_files * sizeof(uint32_t), hipMemcpyHostToDevice,
                                       s.stream));
-        st = enqueue_sha1_resident(lease, arena, d_off, d_len, n_files, d_digests, s.stream, d_epochs, d_arrival);
+        st = enqueue_sha1_resident(lease, arena, d_off, d_len, n_files, d_digests, s.stream, d_epochs, d_arrival,
+                                   group_ends.data(), static_cast<uint32_t>(group_ends.size()));
         if (st != SNAPPY_OK)
             return st;  // nothing was launched that waits
     }
@@ -360,12 +419,12 @@ int import_batch_overlapped(SlotLease &lease, std::vector<StreamJob> &jobs, std:
     // of `run_len`, larger where a chunk takes long next to an archive's transfer.
     hipError_t failure = hipSuccess;
     std::vector<std::pair<size_t, size_t>> launches;  // (first, last + 1) positions in `order` per decode launch
-    const float transfer_ms = static_cast<float>(mean_stream) / 50e6f;  // one archive at PCIe rate
-    size_t run_len = 1;
-    if (whole_chunk_ms > 0.25f * transfer_ms)
-        run_len = std::min<size_t>(8, static_cast<size_t>(4.f * whole_chunk_ms / (transfer_ms > 0.f ? transfer_ms : 1.f)) + 1);
-    if (const char *v = std::getenv("SNAPPY_MCDF_DECODE_RUN"))  // tuning
-        run_len = std::max<size_t>(1, std::strtoul(v, nullptr, 10));
+    // SNAPPY_TRACE_IMPORT=1: host-clock milestones of the overlapped import on stderr (tuning).
+    const bool trace = std::getenv("SNAPPY_TRACE_IMPORT") != nullptr;
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto since = [&] {
+        return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    };
     auto decode_run = [&](size_t from, size_t to) -> hipError_t {
         const uint32_t rows = static_cast<uint32_t>(first_row[to] - first_row[from]);
         // The run's last transfer has been enqueued: everything up to here on the copy stream.
@@ -388,23 +447,41 @@ int import_batch_overlapped(SlotLease &lease, std::vector<StreamJob> &jobs, std:
                                s.decode_stream);
         return e;
     };
-    size_t run_from = 0;
-    for (size_t k = 0; k < order.size() && failure == hipSuccess; ++k) {
-        const size_t a = order[k];
-        std::vector<Piece> whole{{jobs[a].in, jobs[a].in_off, jobs[a].in_len}};
-        failure = transfer_to_device(s, hip_device, whole, kTransferSliceBytes, arena, nullptr, nullptr);
-        if (failure != hipSuccess)
-            break;
-        const bool run_ends = k == 0 || k + 1 == order.size() || k + 1 - run_from >= run_len;
-        if (run_ends) {
-            failure = decode_run(run_from, k + 1);
-            run_from = k + 1;
+    // One transfer for all archives, in arrival order, through the same ring without a pause
+    // between archives (a transfer per archive cost the pipeline's fill and drain 64 times:
+    // 27 GB/s instead of 52); after each archive's last bytes the hook starts its run's decode.
+    {
+        std::vector<Piece> in_order;
+        std::vector<size_t> group_begin;
+        for (size_t k = 0; k < order.size(); ++k) {
+            const size_t a = order[k];
+            group_begin.push_back(in_order.size());
+            in_order.push_back({jobs[a].in, jobs[a].in_off, jobs[a].in_len});
         }
+        size_t run_from = 0;
+        const AfterGroup after_archive = [&](size_t k) -> hipError_t {
+            hipError_t e = hipSuccess;
+            if (run_end_at[k]) {
+                e = decode_run(run_from, k + 1);
+                run_from = k + 1;
+            }
+            if (trace)
+                std::fprintf(stderr, "[import] archive %zu (%.1f MB stream, largest file %.1f MB) handed to the copy stream at %.1f ms%s\n",
+                             k, jobs[order[k]].in_len / 1e6, largest[order[k]] / 1e6, since(), run_end_at[k] ? ", run ends" : "");
+            return e;
+        };
+        if (!in_order.empty())
+            failure = transfer_groups_to_device(s, hip_device, in_order, group_begin, kTransferSliceBytes, arena,
+                                                after_archive);
     }
     if (failure == hipSuccess)
         failure = hipStreamSynchronize(s.copy_stream);
+    if (trace)
+        std::fprintf(stderr, "[import] copy stream drained at %.1f ms\n", since());
     if (failure == hipSuccess)
         failure = hipStreamSynchronize(s.decode_stream);
+    if (trace)
+        std::fprintf(stderr, "[import] decode stream drained at %.1f ms\n", since());
     if (failure != hipSuccess) {
         set_error_detail(std::string("MCDF import, transfer or decode: ") + hipGetErrorString(failure));
         (void)hipGetLastError();
@@ -420,6 +497,9 @@ int import_batch_overlapped(SlotLease &lease, std::vector<StreamJob> &jobs, std:
         uint64_t *d_len = d_off + n_files;
         SNAPPY_HIP_TRY(hipMemcpyAsync(packed.data(), d_digests, n_files * 20, hipMemcpyDeviceToHost, s.stream));
         SNAPPY_HIP_TRY(hipStreamSynchronize(s.stream));
+        if (trace)
+            std::fprintf(stderr, "[import] hashing done at %.1f ms (%zu files in %zu groups)\n", since(), n_files,
+                         group_ends.size());
         Sha1Arrival seen;
         SNAPPY_HIP_TRY(hipMemcpy(&seen, d_arrival, sizeof(seen), hipMemcpyDeviceToHost));
         if (seen.error) {

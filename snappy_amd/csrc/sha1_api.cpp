@@ -176,16 +176,21 @@ void measure_chain_times(SlotLease &lease)
 
 int enqueue_sha1_resident(SlotLease &lease, const uint8_t *d_base, const uint64_t *d_offsets,
                           const uint64_t *d_lengths, uint64_t n, uint8_t *d_digests,
-                          hipStream_t stream, const uint32_t *d_epochs, Sha1Arrival *d_arrival)
+                          hipStream_t stream, const uint32_t *d_epochs, Sha1Arrival *d_arrival,
+                          const uint32_t *group_ends, uint32_t n_groups)
 {
     Slot &s = *lease.slot;
     if (n == 0)
         return SNAPPY_OK;
     if (n >= 0xFFFFFFF0ull)
         return SNAPPY_E_INVALID_ARG;
+    if (group_ends == nullptr)
+        n_groups = 1;
+    if (n_groups == 0 || (group_ends && group_ends[n_groups - 1] != n))
+        return SNAPPY_E_INVALID_ARG;
     int st;
     if ((st = s.d_tasks.ensure(n * sizeof(Sha1Task))) != SNAPPY_OK) return st;
-    if ((st = s.d_misc.ensure(sizeof(Sha1PlanState))) != SNAPPY_OK) return st;
+    if ((st = s.d_misc.ensure(n_groups * sizeof(Sha1PlanState))) != SNAPPY_OK) return st;
     Sha1PlanState *d_state = static_cast<Sha1PlanState *>(s.d_misc.ptr);
     Sha1Task *d_tasks = static_cast<Sha1Task *>(s.d_tasks.ptr);
     const uint32_t n32 = static_cast<uint32_t>(n);
@@ -197,15 +202,27 @@ int enqueue_sha1_resident(SlotLease &lease, const uint8_t *d_base, const uint64_
     const bool prof = profiling_enabled();
     if (prof)
         SNAPPY_HIP_TRY(hipEventRecord(s.ev_prof[0][0], stream));
-    SNAPPY_HIP_TRY(
-        launch_sha1_plan(d_offsets, d_lengths, d_epochs, n32, d_state, d_tasks, model, stream));
+    if (group_ends == nullptr) {
+        SNAPPY_HIP_TRY(launch_sha1_plan(d_offsets, d_lengths, d_epochs, n32, d_state, d_tasks, model, stream));
+    } else {
+        uint32_t first = 0, used = 0;
+        for (uint32_t g = 0; g < n_groups; ++g) {
+            if (group_ends[g] < first)
+                return SNAPPY_E_INVALID_ARG;
+            if (group_ends[g] > first)   // empty groups take no plan
+                SNAPPY_HIP_TRY(launch_sha1_plan(d_offsets, d_lengths, d_epochs, group_ends[g] - first,
+                                                d_state + used++, d_tasks, model, stream, first));
+            first = group_ends[g];
+        }
+        n_groups = used;
+    }
     // Only a batch with at least two full waves of one-lane work per SIMD can be
     // given a second wave per SIMD by the planner: do not launch what must leave.
     const int launch_rounds =
         (d_arrival == nullptr && n >= 128ull * n_simd) ? kMaxWavesPerSimd : 1;
     SNAPPY_HIP_TRY(launch_sha1_hop(d_base, d_tasks, d_state, d_digests, d_arrival, n32, n_simd,
                                    static_cast<int>(env_long("SNAPPY_HOP_GRID_ROUNDS", launch_rounds)),
-                                   stream));
+                                   stream, n_groups));
     if (prof)
         SNAPPY_HIP_TRY(hipEventRecord(s.ev_prof[0][1], stream));
     return SNAPPY_OK;

@@ -26,10 +26,15 @@ int noalloc_setup_device(int hip_device);
 // the caller's message order) are written to d_digests.  Enqueues only.
 // d_epochs / d_arrival (both null, or both set): the data is still being copied
 // to the device; message i is complete once d_arrival->arrived >= d_epochs[i].
+// group_ends (host, n_groups entries, ascending, the last one = n; may be null): the
+// messages arrive in that many groups, in table order; each group is planned on its
+// own and the kernel works them off in order, so that messages that have arrived are
+// not queued behind larger ones that have not.
 int enqueue_sha1_resident(SlotLease &lease, const uint8_t *d_base, const uint64_t *d_offsets,
                           const uint64_t *d_lengths, uint64_t n, uint8_t *d_digests,
                           hipStream_t stream, const uint32_t *d_epochs = nullptr,
-                          Sha1Arrival *d_arrival = nullptr);
+                          Sha1Arrival *d_arrival = nullptr, const uint32_t *group_ends = nullptr,
+                          uint32_t n_groups = 1);
 
 // A kernel that waits for its input (an arrival counter raised by a transfer or by
 // another kernel) keeps one wave on every SIMD for as long as it runs.  Two of them

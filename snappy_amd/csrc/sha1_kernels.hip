@@ -336,60 +336,66 @@ __device__ __forceinline__ HopResult lanes_once(const uint8_t *__restrict__ base
 // that remain still hold two decoder waves or a copy kernel's.
 template <bool kAlone>
 __global__ void __launch_bounds__(kWave)
-sha1_hop_kernel(const uint8_t *__restrict__ base, const Sha1Task *__restrict__ tasks,
-                Sha1PlanState *__restrict__ state, uint8_t *__restrict__ digests,
-                Sha1Arrival *arrival, uint32_t per_simd_round)
+sha1_hop_kernel(const uint8_t *__restrict__ base, const Sha1Task *__restrict__ all_tasks,
+                Sha1PlanState *__restrict__ states, uint8_t *__restrict__ digests,
+                Sha1Arrival *arrival, uint32_t per_simd_round, uint32_t n_groups)
 {
     if constexpr (kAlone)
         asm volatile("" ::: "a15");
     const uint32_t lane = lane_id();
-    if (blockIdx.x >= per_simd_round * __builtin_amdgcn_readfirstlane(state->waves_per_simd))
+    if (blockIdx.x >= per_simd_round * __builtin_amdgcn_readfirstlane(states->waves_per_simd))
         return;
-    uint32_t lo[kSha1Paths], hi[kSha1Paths];
-    float chain[kSha1Paths];
-    bool open[kSha1Paths];
-#pragma unroll
-    for (int k = 0; k < kSha1Paths; ++k) {
-        lo[k] = k ? __builtin_amdgcn_readfirstlane(state->path_end[k - 1]) : 0u;
-        hi[k] = __builtin_amdgcn_readfirstlane(state->path_end[k]);
-        chain[k] = __builtin_amdgcn_readfirstlane(state->chain_ns[k]);
-        open[k] = lo[k] < hi[k];
-    }
-    for (;;) {
-        int best = -1;
-        float best_time = -1.f;
+    // The groups of a batch that arrives piecewise, in the order of their arrival: a wave
+    // that finds a group handed out moves on to the next (and waits there for its data).
+    for (uint32_t g = 0; g < n_groups; ++g) {
+        Sha1PlanState *state = states + g;
+        const Sha1Task *tasks = all_tasks + __builtin_amdgcn_readfirstlane(state->task_base);
+        uint32_t lo[kSha1Paths], hi[kSha1Paths];
+        float chain[kSha1Paths];
+        bool open[kSha1Paths];
 #pragma unroll
         for (int k = 0; k < kSha1Paths; ++k) {
-            if (!open[k])
-                continue;
-            const uint32_t next = __builtin_amdgcn_readfirstlane(
-                __hip_atomic_load(&state->queue[k].next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-            if (next >= hi[k] - lo[k]) {
-                open[k] = false;
-                continue;
-            }
-            const uint64_t len = tasks[lo[k] + next].len;
-            const float t = static_cast<float>((len + 8) / 64 + 1) * chain[k];
-            if (t > best_time) {
-                best_time = t;
-                best = k;
-            }
+            lo[k] = k ? __builtin_amdgcn_readfirstlane(state->path_end[k - 1]) : 0u;
+            hi[k] = __builtin_amdgcn_readfirstlane(state->path_end[k]);
+            chain[k] = __builtin_amdgcn_readfirstlane(state->chain_ns[k]);
+            open[k] = lo[k] < hi[k];
         }
-        if (best < 0)
-            break;
-        // A failed claim only means another wave was quicker: look again.
-        HopResult r;
-        switch (best) {
-        case 0: r = hop_once<64>(base, tasks, lo[0], hi[0], &state->queue[0].next, digests, arrival, lane); break;
-        case 1: r = hop_once<16>(base, tasks, lo[1], hi[1], &state->queue[1].next, digests, arrival, lane); break;
-        case 2: r = hop_once<4>(base, tasks, lo[2], hi[2], &state->queue[2].next, digests, arrival, lane); break;
-        default:
-            r = lanes_once(base, tasks, lo[3], hi[3], &state->queue[3].next, digests, arrival,
-                           reinterpret_cast<const uint8_t *>(state->blocks), lane);
-            break;
+        for (;;) {
+            int best = -1;
+            float best_time = -1.f;
+#pragma unroll
+            for (int k = 0; k < kSha1Paths; ++k) {
+                if (!open[k])
+                    continue;
+                const uint32_t next = __builtin_amdgcn_readfirstlane(
+                    __hip_atomic_load(&state->queue[k].next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                if (next >= hi[k] - lo[k]) {
+                    open[k] = false;
+                    continue;
+                }
+                const uint64_t len = tasks[lo[k] + next].len;
+                const float t = static_cast<float>((len + 8) / 64 + 1) * chain[k];
+                if (t > best_time) {
+                    best_time = t;
+                    best = k;
+                }
+            }
+            if (best < 0)
+                break;
+            // A failed claim only means another wave was quicker: look again.
+            HopResult r;
+            switch (best) {
+            case 0: r = hop_once<64>(base, tasks, lo[0], hi[0], &state->queue[0].next, digests, arrival, lane); break;
+            case 1: r = hop_once<16>(base, tasks, lo[1], hi[1], &state->queue[1].next, digests, arrival, lane); break;
+            case 2: r = hop_once<4>(base, tasks, lo[2], hi[2], &state->queue[2].next, digests, arrival, lane); break;
+            default:
+                r = lanes_once(base, tasks, lo[3], hi[3], &state->queue[3].next, digests, arrival,
+                               reinterpret_cast<const uint8_t *>(state->blocks), lane);
+                break;
+            }
+            if (r == kHopGiveUp)
+                return;
         }
-        if (r == kHopGiveUp)
-            break;
     }
 }
 
@@ -397,7 +403,7 @@ sha1_hop_kernel(const uint8_t *__restrict__ base, const Sha1Task *__restrict__ t
 
 hipError_t launch_sha1_hop(const uint8_t *d_base, const Sha1Task *d_tasks, Sha1PlanState *d_state,
                            uint8_t *d_digests, Sha1Arrival *d_arrival, uint32_t n, uint32_t n_simd,
-                           int waves_per_simd, hipStream_t stream)
+                           int waves_per_simd, hipStream_t stream, uint32_t n_groups)
 {
     if (n == 0)
         return hipSuccess;
@@ -406,10 +412,10 @@ hipError_t launch_sha1_hop(const uint8_t *d_base, const Sha1Task *d_tasks, Sha1P
     const uint32_t per = n < n_simd ? n : n_simd;
     if (waves_per_simd <= 1)
         hipLaunchKernelGGL(sha1_hop_kernel<true>, dim3(per), dim3(kWave), 0, stream, d_base, d_tasks, d_state,
-                           d_digests, d_arrival, per);
+                           d_digests, d_arrival, per, n_groups);
     else
         hipLaunchKernelGGL(sha1_hop_kernel<false>, dim3(per * static_cast<uint32_t>(waves_per_simd)),
-                           dim3(kWave), 0, stream, d_base, d_tasks, d_state, d_digests, d_arrival, per);
+                           dim3(kWave), 0, stream, d_base, d_tasks, d_state, d_digests, d_arrival, per, n_groups);
     return hipGetLastError();
 }
 

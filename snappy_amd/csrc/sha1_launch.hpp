@@ -49,7 +49,7 @@ struct Sha1PlanState {
     double planned_ns;                // the model's finishing time for the chosen cut
     float chain_ns[kSha1Paths];       // the model's chain times, for the kernel's work order
     uint32_t waves_per_simd;          // 1: chains decide the finishing time; 2: bulk throughput
-    uint32_t reserved0;
+    uint32_t task_base;               // index of this plan's first task in the batch's task list
     // Address range of the batch: the largest ~offset (i.e. the smallest offset, kept this way so
     // that the zeroed header is the neutral start) and the largest end.
     unsigned long long span_lo_inverted;
@@ -78,18 +78,26 @@ struct Sha1Arrival {
 
 // Sorts the n messages by descending padded size into d_tasks and cuts the
 // sorted list into the paths' ranges (see sha1_plan.hip).  d_epochs (may be
-// null) gives each message's Sha1Task::ready_epoch.
+// null) gives each message's Sha1Task::ready_epoch.  `first`: the messages are
+// entries [first, first + n) of the batch's tables (the pointers are the tables'
+// starts); their tasks go to d_tasks[first ..] and report to digest slots first + i.
+// A batch planned in several such groups takes one Sha1PlanState per group.
 hipError_t launch_sha1_plan(const uint64_t *d_offsets, const uint64_t *d_lengths,
                             const uint32_t *d_epochs, uint32_t n, Sha1PlanState *d_state,
-                            Sha1Task *d_tasks, const Sha1CostModel &model, hipStream_t stream);
+                            Sha1Task *d_tasks, const Sha1CostModel &model, hipStream_t stream,
+                            uint32_t first = 0);
 
 // Hashes the planned batch.  n_simd * kMaxWavesPerSimd single-wave workgroups are
 // launched (fewer for small batches); those beyond the planner's waves_per_simd
 // leave at once, the others take work, longest chains first, until none is left.
 constexpr int kMaxWavesPerSimd = 2;
-// d_arrival (may be null): see Sha1Arrival.
+// d_arrival (may be null): see Sha1Arrival.  n_groups plans (d_state[0 .. n_groups)) are
+// worked off one after the other by the same waves: a batch whose data arrives in
+// groups is planned group by group, so that what has arrived is never queued behind
+// what has not.
 hipError_t launch_sha1_hop(const uint8_t *d_base, const Sha1Task *d_tasks,
                            Sha1PlanState *d_state, uint8_t *d_digests, Sha1Arrival *d_arrival,
-                           uint32_t n, uint32_t n_simd, int waves_per_simd, hipStream_t stream);
+                           uint32_t n, uint32_t n_simd, int waves_per_simd, hipStream_t stream,
+                           uint32_t n_groups = 1);
 
 }  // namespace snappy

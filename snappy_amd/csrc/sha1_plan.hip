@@ -135,7 +135,7 @@ __device__ __forceinline__ double candidate_d(int c, double d_top, double max_bl
 }
 
 __global__ void __launch_bounds__(kPlanBuckets)
-plan_scan(Sha1PlanState *__restrict__ st, uint32_t n, Sha1CostModel m)
+plan_scan(Sha1PlanState *__restrict__ st, uint32_t n, Sha1CostModel m, uint32_t first)
 {
     __shared__ uint32_t scan[kPlanBuckets];
     __shared__ uint32_t used[kPlanBuckets];   // positions of the non-empty buckets
@@ -310,6 +310,7 @@ plan_scan(Sha1PlanState *__restrict__ st, uint32_t n, Sha1CostModel m)
     if (m.forced_waves > 0)
         waves = m.forced_waves < kMaxWavesPerSimd ? m.forced_waves : kMaxWavesPerSimd;
     st->waves_per_simd = waves;
+    st->task_base = first;
     // The cut minimises the list-scheduling BOUND max(longest, load + late).  What is reported is the
     // expected finishing time under it: the pieces that wait for a SIMD are handed out longest first,
     // so what sticks out over the average load at the end is on average half a late piece, and a
@@ -324,7 +325,7 @@ plan_scan(Sha1PlanState *__restrict__ st, uint32_t n, Sha1CostModel m)
 __global__ void __launch_bounds__(kPlanThreads)
 plan_scatter(const uint64_t *__restrict__ offsets, const uint64_t *__restrict__ lengths,
              const uint32_t *__restrict__ epochs, uint32_t n, Sha1PlanState *__restrict__ st,
-             Sha1Task *__restrict__ tasks)
+             Sha1Task *__restrict__ tasks, uint32_t first)
 {
     __shared__ uint32_t local[kPlanBuckets];
     __shared__ uint32_t base_of[kPlanBuckets];
@@ -354,7 +355,7 @@ plan_scatter(const uint64_t *__restrict__ offsets, const uint64_t *__restrict__ 
             Sha1Task t;
             t.offset = offsets[i];
             t.len = lengths[i];
-            t.out_index = i;
+            t.out_index = first + i;
             t.ready_epoch = epochs ? epochs[i] : 0u;
             tasks[base_of[bucket[j]] + slot[j]] = t;
         }
@@ -366,7 +367,7 @@ plan_scatter(const uint64_t *__restrict__ offsets, const uint64_t *__restrict__ 
 // path).  A single GetHash call is three kernel launches shorter for it.
 __global__ void plan_single(const uint64_t *__restrict__ offsets, const uint64_t *__restrict__ lengths,
                             const uint32_t *__restrict__ epochs, Sha1PlanState *__restrict__ st,
-                            Sha1Task *__restrict__ tasks, Sha1CostModel m)
+                            Sha1Task *__restrict__ tasks, Sha1CostModel m, uint32_t first)
 {
     if (threadIdx.x != 0)
         return;
@@ -381,10 +382,11 @@ __global__ void plan_single(const uint64_t *__restrict__ offsets, const uint64_t
     st->max_blocks = blocks;
     st->planned_ns = m.forced_path >= 0 ? 0.0 : static_cast<double>(blocks) * m.chain_ns[0];
     st->waves_per_simd = 1;
+    st->task_base = first;
     Sha1Task t;
     t.offset = offsets[0];
     t.len = lengths[0];
-    t.out_index = 0;
+    t.out_index = first;
     t.ready_epoch = epochs ? epochs[0] : 0u;
     tasks[0] = t;
 }
@@ -393,13 +395,18 @@ __global__ void plan_single(const uint64_t *__restrict__ offsets, const uint64_t
 
 hipError_t launch_sha1_plan(const uint64_t *d_offsets, const uint64_t *d_lengths,
                             const uint32_t *d_epochs, uint32_t n, Sha1PlanState *d_state,
-                            Sha1Task *d_tasks, const Sha1CostModel &model, hipStream_t stream)
+                            Sha1Task *d_tasks, const Sha1CostModel &model, hipStream_t stream, uint32_t first)
 {
     if (n == 0)
         return hipSuccess;
+    d_offsets += first;
+    d_lengths += first;
+    if (d_epochs)
+        d_epochs += first;
+    d_tasks += first;
     if (n == 1) {
         hipLaunchKernelGGL(plan_single, dim3(1), dim3(64), 0, stream, d_offsets, d_lengths, d_epochs,
-                           d_state, d_tasks, model);
+                           d_state, d_tasks, model, first);
         return hipGetLastError();
     }
     hipError_t e = hipMemsetAsync(d_state, 0, sizeof(Sha1PlanState), stream);
@@ -409,9 +416,9 @@ hipError_t launch_sha1_plan(const uint64_t *d_offsets, const uint64_t *d_lengths
     const uint32_t groups = (n + per_group - 1) / per_group;
     hipLaunchKernelGGL(plan_histogram, dim3(groups), dim3(kPlanThreads), 0, stream, d_offsets, d_lengths, n,
                        d_state);
-    hipLaunchKernelGGL(plan_scan, dim3(1), dim3(kPlanBuckets), 0, stream, d_state, n, model);
+    hipLaunchKernelGGL(plan_scan, dim3(1), dim3(kPlanBuckets), 0, stream, d_state, n, model, first);
     hipLaunchKernelGGL(plan_scatter, dim3(groups), dim3(kPlanThreads), 0, stream, d_offsets,
-                       d_lengths, d_epochs, n, d_state, d_tasks);
+                       d_lengths, d_epochs, n, d_state, d_tasks, first);
     return hipGetLastError();
 }
 

@@ -22,11 +22,14 @@ constexpr unsigned kStageThreads = 6;
 // bytes lie.
 hipError_t transfer_direct(Slot &s, const std::vector<Piece> &pieces, uint64_t slice_bytes,
                            uint64_t n_slices, uint8_t *d_base, uint32_t *d_progress,
-                           const uint32_t *slice_numbers, SourceGate *gate)
+                           const uint32_t *slice_numbers, SourceGate *gate,
+                           const std::vector<size_t> *group_begin = nullptr, const AfterGroup *after_group = nullptr)
 {
     hipError_t e = hipSuccess;
     uint64_t next_mark = 1;  // slice whose end has not been marked yet
-    for (const Piece &c : pieces) {
+    size_t group = 0;
+    for (size_t ci = 0; ci < pieces.size(); ++ci) {
+        const Piece &c = pieces[ci];
         uint64_t done = 0;
         while (done < c.len && e == hipSuccess) {
             const uint64_t pos = c.dst + done;
@@ -47,6 +50,14 @@ hipError_t transfer_direct(Slot &s, const std::vector<Piece> &pieces, uint64_t s
         }
         if (e != hipSuccess)
             return e;
+        if (group_begin && after_group) {
+            const size_t group_end = group + 1 < group_begin->size() ? (*group_begin)[group + 1] : pieces.size();
+            if (ci + 1 == group_end) {
+                if ((e = (*after_group)(group)) != hipSuccess)
+                    return e;
+                ++group;
+            }
+        }
     }
     if (!d_progress)
         return hipSuccess;
@@ -62,27 +73,68 @@ hipError_t transfer_direct(Slot &s, const std::vector<Piece> &pieces, uint64_t s
 // the PCIe link.
 hipError_t transfer_staged(Slot &s, int hip_device, const std::vector<Piece> &pieces,
                            uint64_t slice_bytes, uint64_t n_slices, uint8_t *d_base,
-                           uint32_t *d_progress, const uint32_t *slice_numbers, SourceGate *gate)
+                           uint32_t *d_progress, const uint32_t *slice_numbers, SourceGate *gate,
+                           const std::vector<size_t> *group_begin = nullptr, const AfterGroup *after_group = nullptr)
 {
     struct Segment {
         const uint8_t *src;
         uint64_t dst, len;
     };
+    // Slices are cut in arena coordinates, so that a slice is one contiguous range of the arena
+    // and leaves the ring in one copy however many pieces it holds.  Groups (see
+    // transfer_groups_to_device) lie anywhere in the arena: each is sliced on its own, from
+    // the slice boundary below its first byte, and the groups' slices are numbered one after the
+    // other in the order the groups were given.
     std::vector<Segment> segs;
-    std::vector<size_t> seg_begin(n_slices + 1, 0);
-    for (const Piece &c : pieces) {
-        uint64_t done = 0;
-        while (done < c.len) {
-            const uint64_t pos = c.dst + done;
-            const uint64_t slice = pos / slice_bytes;
-            const uint64_t take = std::min<uint64_t>(c.len - done, (slice + 1) * slice_bytes - pos);
-            segs.push_back({c.src + done, pos, take});
-            ++seg_begin[slice + 1];
-            done += take;
+    std::vector<uint64_t> slice_start;   // arena offset a slice's ring buffer starts at
+    std::vector<size_t> seg_count;       // segments per slice
+    std::vector<size_t> group_last_slice;  // per group: its last slice (SIZE_MAX: no bytes)
+    {
+        const size_t n_groups = group_begin ? group_begin->size() : 1;
+        for (size_t g = 0; g < n_groups; ++g) {
+            const size_t lo = group_begin ? (*group_begin)[g] : 0;
+            const size_t hi = (group_begin && g + 1 < n_groups) ? (*group_begin)[g + 1] : pieces.size();
+            const size_t first_slice = slice_start.size();
+            uint64_t base = 0;
+            bool have_base = false;
+            for (size_t ci = lo; ci < hi; ++ci) {
+                const Piece &c = pieces[ci];
+                uint64_t done = 0;
+                while (done < c.len) {
+                    const uint64_t pos = c.dst + done;
+                    if (!have_base) {
+                        base = group_begin ? pos / slice_bytes * slice_bytes : 0;
+                        have_base = true;
+                    }
+                    const uint64_t local = (pos - base) / slice_bytes;
+                    while (slice_start.size() <= first_slice + local) {
+                        slice_start.push_back(base + (slice_start.size() - first_slice) * slice_bytes);
+                        seg_count.push_back(0);
+                    }
+                    const uint64_t take = std::min<uint64_t>(c.len - done, base + (local + 1) * slice_bytes - pos);
+                    segs.push_back({c.src + done, pos, take});
+                    ++seg_count[first_slice + local];
+                    done += take;
+                }
+            }
+            group_last_slice.push_back(slice_start.size() > first_slice ? slice_start.size() - 1 : SIZE_MAX);
         }
     }
+    if (!group_begin)   // one group from arena offset 0: the caller's slice numbering (the progress counter's)
+        while (slice_start.size() < n_slices) {
+            slice_start.push_back(slice_start.size() * slice_bytes);
+            seg_count.push_back(0);
+        }
+    n_slices = slice_start.size();
+    if (n_slices == 0) {   // nothing to move: the groups are "sent"
+        hipError_t e0 = hipSuccess;
+        for (size_t g = 0; after_group && g < group_last_slice.size() && e0 == hipSuccess; ++g)
+            e0 = (*after_group)(g);
+        return e0;
+    }
+    std::vector<size_t> seg_begin(n_slices + 1, 0);
     for (uint64_t k = 0; k < n_slices; ++k)
-        seg_begin[k + 1] += seg_begin[k];
+        seg_begin[k + 1] = seg_begin[k] + seg_count[k];
 
     // No more ring than the batch has slices (a small batch must not pin 192 MiB).
     const unsigned ring_slots = static_cast<unsigned>(std::min<uint64_t>(kRingSlots, n_slices));
@@ -127,7 +179,7 @@ hipError_t transfer_staged(Slot &s, int hip_device, const std::vector<Piece> &pi
             for (size_t q = seg_begin[k]; q < seg_begin[k + 1]; ++q) {
                 if (gate)
                     gate->wait_for(segs[q].src, segs[q].len);
-                std::memcpy(slot + (segs[q].dst - k * slice_bytes), segs[q].src, segs[q].len);
+                std::memcpy(slot + (segs[q].dst - slice_start[k]), segs[q].src, segs[q].len);
             }
             {
                 std::lock_guard<std::mutex> g(mu);
@@ -150,6 +202,12 @@ hipError_t transfer_staged(Slot &s, int hip_device, const std::vector<Piece> &pi
     }
 
     hipError_t e = hipSuccess;
+    size_t group = 0;
+    auto groups_done_through = [&](uint64_t k) {   // groups whose last slice is k (or that hold no bytes)
+        while (e == hipSuccess && after_group && group < group_last_slice.size() &&
+               (group_last_slice[group] == SIZE_MAX || group_last_slice[group] <= k))
+            e = (*after_group)(group++);
+    };
     for (uint64_t k = 0; k < n_slices && e == hipSuccess; ++k) {
         {
             std::unique_lock<std::mutex> lk(mu);
@@ -163,7 +221,7 @@ hipError_t transfer_staged(Slot &s, int hip_device, const std::vector<Piece> &pi
             const uint64_t lo = segs[seg_begin[k]].dst;
             const Segment &last = segs[seg_begin[k + 1] - 1];
             const uint64_t hi = last.dst + last.len;
-            e = hipMemcpyAsync(d_base + lo, ring + (k % ring_slots) * slice_bytes + (lo - k * slice_bytes),
+            e = hipMemcpyAsync(d_base + lo, ring + (k % ring_slots) * slice_bytes + (lo - slice_start[k]),
                                hi - lo, hipMemcpyHostToDevice, s.copy_stream);
         }
         if (e == hipSuccess && d_progress)
@@ -171,6 +229,7 @@ hipError_t transfer_staged(Slot &s, int hip_device, const std::vector<Piece> &pi
                                hipMemcpyHostToDevice, s.copy_stream);
         if (e == hipSuccess)
             e = hipEventRecord(sent[k % ring_slots], s.copy_stream);
+        groups_done_through(k);
         {
             std::lock_guard<std::mutex> g(mu);
             if (e == hipSuccess)
@@ -371,6 +430,24 @@ hipError_t transfer_to_device(Slot &s, int hip_device, const std::vector<Piece> 
                                            d_progress, slice_numbers, gate)
                          : transfer_direct(s, pieces, slice_bytes, n_slices, d_base, d_progress,
                                            slice_numbers, gate);
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(s.copy_stream);
+    return e;
+}
+
+hipError_t transfer_groups_to_device(Slot &s, int hip_device, const std::vector<Piece> &pieces,
+                                     const std::vector<size_t> &group_begin, uint64_t slice_bytes,
+                                     uint8_t *d_base, const AfterGroup &after_group)
+{
+    uint64_t bytes = 0;
+    for (const Piece &c : pieces)
+        bytes += c.len;
+    const char *env = std::getenv("SNAPPY_STAGE_PAGEABLE");  // "0": never stage (tuning)
+    const bool stage = !(env && env[0] == '0') && bytes >= (8ull << 20) && !sources_are_page_locked(pieces);
+    hipError_t e = stage ? transfer_staged(s, hip_device, pieces, slice_bytes, 0, d_base, nullptr, nullptr, nullptr,
+                                           &group_begin, &after_group)
+                         : transfer_direct(s, pieces, slice_bytes, 0, d_base, nullptr, nullptr, nullptr,
+                                           &group_begin, &after_group);
     if (e == hipSuccess)
         e = hipStreamSynchronize(s.copy_stream);
     return e;

@@ -6,6 +6,7 @@
 // kernels that start before their input has arrived.
 #pragma once
 
+#include <functional>
 #include <vector>
 
 #include "runtime.hpp"
@@ -37,6 +38,18 @@ struct SourceGate {
 hipError_t transfer_to_device(Slot &s, int hip_device, const std::vector<Piece> &pieces,
                               uint64_t slice_bytes, uint8_t *d_base, uint32_t *d_progress,
                               const uint32_t *slice_numbers, SourceGate *gate = nullptr);
+
+// The same for pieces that form groups which may lie anywhere in the arena and are sent in the
+// order given (an import's archives in the order their files are wanted): group g is
+// pieces [group_begin[g], group_begin[g + 1]) (the last group ends with the last piece), in
+// arena order inside the group.  The groups follow each other through the same ring without
+// a pause; after_group(g) is called on the calling thread as soon as the last bytes of group
+// g have been handed to the copy stream (what it enqueues there or on a stream that waits for
+// an event recorded there runs behind them).  A failure it returns ends the transfer.
+using AfterGroup = std::function<hipError_t(size_t)>;
+hipError_t transfer_groups_to_device(Slot &s, int hip_device, const std::vector<Piece> &pieces,
+                                     const std::vector<size_t> &group_begin, uint64_t slice_bytes,
+                                     uint8_t *d_base, const AfterGroup &after_group);
 
 // The other direction: bytes of device memory to a host buffer, after all work on
 // the slot's main stream has finished (the caller has synchronised it).  Ordinary
