@@ -414,17 +414,27 @@ def test_mcdf_import_overlapped_path(snappy, oracle, monkeypatch):
     plain = snappy.mcdf_decode_and_hash_batch(streams)
     check(plain, streams)
     monkeypatch.setenv("SNAPPY_OVERLAP_MIN_BYTES", "0")
-    for waiting_kernel in ("1", "1", None):
-        # With archives this small the library itself would send everything, decode it in one
-        # launch and hash afterwards (the third turn); the first two force the waiting kernel.
-        if waiting_kernel:
-            monkeypatch.setenv("SNAPPY_MCDF_FORCE_OVERLAP", waiting_kernel)
-        else:
-            monkeypatch.delenv("SNAPPY_MCDF_FORCE_OVERLAP")
+    for turn in ("waiting kernel", "waiting kernel", "one decode launch per archive", "plain order"):
+        # Archives this small normally take the short way (send, decode, hash); with the size
+        # limit at 0 they go through the overlapped import: the SHA-1 kernel waiting, the files
+        # planned group by group in arrival order; the last turn sends everything first.
+        monkeypatch.delenv("SNAPPY_MCDF_PLAIN_ORDER", raising=False)
+        monkeypatch.delenv("SNAPPY_MCDF_DECODE_RUN", raising=False)
+        if turn == "plain order":
+            monkeypatch.setenv("SNAPPY_MCDF_PLAIN_ORDER", "1")
+        if turn == "one decode launch per archive":
+            monkeypatch.setenv("SNAPPY_MCDF_DECODE_RUN", "1")
         over = snappy.mcdf_decode_and_hash_batch(streams)
         check(over, streams)
         for a, b in zip(plain, over):
-            assert a["status"] == b["status"] and np.array_equal(a["digests"], b["digests"])
+            assert a["status"] == b["status"] and np.array_equal(a["digests"], b["digests"]), turn
+    monkeypatch.delenv("SNAPPY_MCDF_PLAIN_ORDER", raising=False)
+    # 75 archives, one decode launch each: more runs than hashing groups (64), so groups of two runs.
+    monkeypatch.setenv("SNAPPY_MCDF_DECODE_RUN", "1")
+    pool = [_make_archive(oracle, 2 + k, 300 + k, chunk=1 << 15)[0] for k in range(9)] + [broken, b""]
+    many_archives = [pool[(7 * i) % len(pool)] for i in range(75)]
+    check(snappy.mcdf_decode_and_hash_batch(many_archives), many_archives)
+    monkeypatch.delenv("SNAPPY_MCDF_DECODE_RUN", raising=False)
     single = snappy.mcdf_decode_and_hash(good[0], want_payload=True)
     assert single["payload"] == oracle.mcdf_import(good[0])["payload"]
     # 600 files, 4 KiB chunks: the header JSON is longer than the first chunk
