@@ -347,28 +347,48 @@ public:
     }
     int acquire(uint64_t bytes)
     {
+        // Page-locked memory is allocated and freed with the arena's lock released: those calls
+        // go through the library's initialisation lock, which snappy_shutdown holds while it takes
+        // the arena's (release_file_arena).  The arena is marked busy first, so nobody else
+        // touches it meanwhile.
+        void *stale = nullptr;
+        bool too_small = false;
         {
             std::lock_guard<std::mutex> lk(g_file_arena.mu);
             if (!g_file_arena.busy) {
-                if (g_file_arena.cap < bytes) {
-                    if (g_file_arena.ptr)
-                        (void)snappy_host_free(g_file_arena.ptr);
-                    g_file_arena.ptr = nullptr;
-                    g_file_arena.cap = 0;
-                    const uint64_t want = bytes + bytes / 4;
-                    int st = snappy_host_alloc(want, &g_file_arena.ptr);
-                    if (st != SNAPPY_OK)
-                        return st;
-                    g_file_arena.cap = want;
-                }
                 g_file_arena.busy = true;
                 shared_ = true;
-                ptr_ = g_file_arena.ptr;
-                return SNAPPY_OK;
+                if (g_file_arena.cap < bytes) {
+                    too_small = true;
+                    stale = g_file_arena.ptr;
+                    g_file_arena.ptr = nullptr;
+                    g_file_arena.cap = 0;
+                } else {
+                    ptr_ = g_file_arena.ptr;
+                }
             }
         }
-        own_cap_ = bytes;
-        return snappy_host_alloc(bytes, &ptr_);
+        if (!shared_) {
+            own_cap_ = bytes;
+            return snappy_host_alloc(bytes, &ptr_);
+        }
+        if (!too_small)
+            return SNAPPY_OK;
+        if (stale)
+            (void)snappy_host_free(stale);
+        const uint64_t want = bytes + bytes / 4;
+        void *fresh = nullptr;
+        const int st = snappy_host_alloc(want, &fresh);
+        std::lock_guard<std::mutex> lk(g_file_arena.mu);
+        if (st != SNAPPY_OK) {
+            g_file_arena.busy = false;
+            shared_ = false;
+            return st;
+        }
+        g_file_arena.ptr = fresh;
+        g_file_arena.cap = want;
+        ptr_ = fresh;
+        return SNAPPY_OK;
     }
     // Makes room for `bytes`, keeping the first `keep` bytes.
     int grow(uint64_t bytes, uint64_t keep)

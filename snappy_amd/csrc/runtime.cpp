@@ -108,20 +108,39 @@ int init_locked(int n_devices)
     if (n_devices > 0 && static_cast<size_t>(n_devices) < usable.size())
         usable.resize(static_cast<size_t>(n_devices));
 
+    // Binding makes each device current in turn (the no-allocation entry point's planning
+    // area is looked up per device): the caller's current device is put back afterwards, and
+    // a failure on the way leaves nothing half bound.
+    int callers_device = -1;
+    if (hipGetDevice(&callers_device) != hipSuccess) {
+        (void)hipGetLastError();
+        callers_device = -1;
+    }
+    int status = SNAPPY_OK;
     for (int d : usable) {
         auto ctx = std::make_unique<DeviceCtx>();
         ctx->hip_device = d;
         hipDeviceProp_t prop;
-        SNAPPY_HIP_TRY(hipGetDeviceProperties(&prop, d));
-        ctx->n_cu = prop.multiProcessorCount;
-        SNAPPY_HIP_TRY(hipSetDevice(d));
-        int st = noalloc_setup_device(d);
-        if (st != SNAPPY_OK) {
-            g_devices.clear();
-            g_init_status = st;
-            return st;
+        hipError_t e = hipGetDeviceProperties(&prop, d);
+        if (e == hipSuccess)
+            e = hipSetDevice(d);
+        if (e != hipSuccess) {
+            set_error_detail(std::string("binding device: ") + hipGetErrorString(e));
+            (void)hipGetLastError();
+            status = SNAPPY_E_HIP;
+            break;
         }
+        ctx->n_cu = prop.multiProcessorCount;
+        if ((status = noalloc_setup_device(d)) != SNAPPY_OK)
+            break;
         g_devices.push_back(std::move(ctx));
+    }
+    if (callers_device >= 0)
+        (void)hipSetDevice(callers_device);
+    if (status != SNAPPY_OK) {
+        g_devices.clear();
+        g_init_status = status;
+        return status;
     }
     g_initialized = true;
     g_init_status = SNAPPY_OK;
