@@ -318,6 +318,7 @@ def run_mcdf(args, rank, world, local_rank, dist):
         sha_ms.append(lib.snappy_profile_last_ms(0))
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    first_group_plan = last_plan(lib)   # of the archive that arrives first: the one with the largest file
     job_bytes = float(out_bytes)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64)
@@ -372,6 +373,13 @@ def run_mcdf(args, rank, world, local_rank, dist):
                      "import_decode_launches_ms": float(np.mean(lz4_ms)),
                      "import_decode_launches_over_one_launch": float(np.mean(lz4_ms)) / k_lz4,
                      "sha1_kernel_ms": float(np.mean(sha_ms)),
+                     # The hashing is planned group by group in arrival order; this is the first group's plan
+                     # (the archive holding the batch's largest file): its planned_ms is that file's chain, the
+                     # floor under the whole import next to one archive's transfer and decode.
+                     "sha1_plan_first_group": first_group_plan,
+                     "import_ms_over_first_group_planned_ms":
+                         (elapsed / args.steps * 1e3 / first_group_plan["planned_ms"])
+                         if first_group_plan and first_group_plan["planned_ms"] > 0 else None,
                      # What a plain device-to-device copy of the decoded size moves on this box (read + write):
                      # the practical ceiling next to the 8 TB/s of the data sheet.
                      "device_copy_GBps_measured": device_copy_rate(torch, min(out_bytes, 2 << 30))},

@@ -69,34 +69,34 @@ struct InputWindow {
     // to the compiler lands where the paths join again, is executed by every
     // token, and waits for whatever stores are in flight by then as well (loads
     // and stores share one in-order counter).
-    template <uint32_t kBlocks>
-    __device__ __forceinline__ void load_blocks(uint32_t blk, uint32_t slot, uint32_t lane)
+    //
+    // The bytes go from memory straight into LDS (global_load_lds_dwordx4: 16 bytes per lane,
+    // 1 KiB = four blocks per instruction, no vector registers on the way), so all of a trip's
+    // loads are in flight together and one wait covers them; through registers a trip of 6 KiB
+    // was three round trips one after the other, a sixth of the parsing wave's time on streams
+    // of short sequences.  A piece that would reach past the readable bytes is taken from the
+    // chunk's first bytes instead: no position at or beyond the chunk's end is ever parsed, so
+    // what the stage holds there does not matter.
+    __device__ __forceinline__ void load_kib(uint32_t blk, uint32_t slot, uint32_t n_kib, uint32_t lane)
     {
-        uint32_t w[kBlocks];
-#pragma unroll
-        for (uint32_t q = 0; q < kBlocks; ++q) {
-            const uint32_t idx = (blk + q) * 64u + lane;
-            w[q] = aligned[idx < limit_dwords ? idx : 0u];
-            w[q] = idx < limit_dwords ? w[q] : 0u;
+        for (uint32_t g = 0; g < n_kib; ++g) {
+            const uint32_t idx = (blk + 4u * g) * 64u + 4u * lane;   // first dword of this lane's 16 bytes
+            const uint32_t *from = aligned + (idx + 4u <= limit_dwords && idx + 4u > idx ? idx : 0u);
+            __builtin_amdgcn_global_load_lds(from, stage + (slot + 4u * g) * 64u, 16, 0, 0);
         }
-        wait_for_memory();
-#pragma unroll
-        for (uint32_t q = 0; q < kBlocks; ++q)
-            stage[(slot + q) * 64u + lane] = w[q];
     }
 
     // Stages the blocks from `blk` on: all of them when the parser ran off the end
     // of what was staged (tokens are dense here), a few after a jump.
     __device__ __forceinline__ void restage(uint32_t blk, bool all, uint32_t lane)
     {
-        load_blocks<kJumpBlocks>(blk, 0, lane);
-        stage_count = kJumpBlocks;
-        if (all) {
-            load_blocks<(kStageBlocks - kJumpBlocks) / 2u>(blk + kJumpBlocks, kJumpBlocks, lane);
-            load_blocks<(kStageBlocks - kJumpBlocks) / 2u>(blk + (kStageBlocks + kJumpBlocks) / 2u,
-                                                           (kStageBlocks + kJumpBlocks) / 2u, lane);
-            stage_count = kStageBlocks;
-        }
+        static_assert(kJumpBlocks % 4u == 0 && kStageBlocks % 4u == 0, "staged 1 KiB at a time");
+        // The LDS reads of the old content have returned before it is overwritten.
+        wait_for_lds();
+        load_kib(blk, 0, (all ? kStageBlocks : kJumpBlocks) / 4u, lane);
+        wait_for_memory();
+        asm volatile("" ::: "memory");
+        stage_count = all ? kStageBlocks : kJumpBlocks;
         stage_block = blk;
     }
 
@@ -1238,7 +1238,7 @@ lz4_decode_kernel(const uint8_t *__restrict__ in_base, uint64_t in_alloc, uint8_
 {
     __shared__ __attribute__((aligned(16))) uint8_t ring[kHist];
     const uint32_t lane = threadIdx.x & (kWave - 1);
-    __shared__ uint32_t stage[kStageBlocks * 64u];
+    __shared__ __attribute__((aligned(16))) uint32_t stage[kStageBlocks * 64u];
     // In an MCDF import the decoder runs next to a SHA-1 kernel whose waves issue an
     // instruction in nearly every slot of their SIMD.  A decoder wave spends most of its
     // time waiting for memory and LDS; when it is ready it should not queue behind that.
@@ -1273,7 +1273,7 @@ lz4_decode_pair_kernel(const uint8_t *__restrict__ in_base, uint64_t in_alloc, u
                        uint32_t *__restrict__ queue, uint32_t *__restrict__ status, uint32_t tuning)
 {
     __shared__ __attribute__((aligned(16))) uint8_t ring[kHist];
-    __shared__ uint32_t stage[kStageBlocks * 64u];
+    __shared__ __attribute__((aligned(16))) uint32_t stage[kStageBlocks * 64u];
     __shared__ TeamShared shared;
     const uint32_t lane = threadIdx.x & (kWave - 1);
     // The parser's chain of dependent steps is what a chunk's time hangs on: when its
