@@ -833,13 +833,23 @@ __device__ __forceinline__ void batch_matches(uint8_t *dst, uint8_t *ring, const
     const uint32_t *from32 = reinterpret_cast<const uint32_t *>(from0 & ~uintptr_t(3));
     LaneCopy fc(mo, far_len, 0);
     fc.m = static_cast<uint32_t>(from0) & 3u;
-    uint32_t fw[kFarStep + 1u];
-    if (any_far) {
+    // Two steps of source dwords are kept in flight: a step is 40 bytes, and one round trip after
+    // the other the steps of long matches (200 bytes: five) took more of the helper's time on
+    // such streams than everything else it does.
+    uint32_t fw[kFarStep + 1u], fx[kFarStep + 1u];
+    auto far_loads = [&](uint32_t k0, uint32_t (&to)[kFarStep + 1u]) {
 #pragma unroll
         for (uint32_t i = 0; i <= kFarStep; ++i) {
-            const uint32_t *at = from32 + (fc.wants(i) ? i : 0u);
-            fw[i] = *(at < floor32 ? floor32 : at);
+            const uint32_t *at = from32 + (fc.wants(k0 + i) ? k0 + i : 0u);
+            to[i] = *(at < floor32 ? floor32 : at);
         }
+    };
+    bool far_second = false;
+    if (any_far) {
+        far_loads(0, fw);
+        far_second = __builtin_amdgcn_ballot_w64(kFarStep < fc.count) != 0;
+        if (far_second)
+            far_loads(kFarStep, fx);
     }
 
     // Matches that read the ring are copied in rounds: a match is copied once every
@@ -875,26 +885,28 @@ __device__ __forceinline__ void batch_matches(uint8_t *dst, uint8_t *ring, const
         // step that holds them keeps them (a step's dwords are registers, not memory).
         uint32_t t0 = 0, t1 = 0;
         const uint32_t last = fc.count ? fc.count - 1u : 0u;
-        wait_for_memory();
-#pragma unroll
-        for (uint32_t i = 0; i < kFarStep; ++i) {
-            t0 = (i == last) ? fw[i] : t0;
-            t1 = (i == last) ? fw[i + 1u] : t1;
-        }
-        lane_copy_step<kFarStep>(ring, fc, 0, fw);
-        for (uint32_t k0 = kFarStep; __builtin_amdgcn_ballot_w64(k0 < fc.count) != 0; k0 += kFarStep) {
-#pragma unroll
-            for (uint32_t i = 0; i <= kFarStep; ++i) {
-                const uint32_t *at = from32 + (fc.wants(k0 + i) ? k0 + i : 0u);
-                fw[i] = *(at < floor32 ? floor32 : at);
-            }
-            wait_for_memory();
+        // fw: step k0 (wanted now), fx: step k0 + kFarStep (in flight), fy: the one after, asked
+        // for before fw is waited for.  Loads return in order and the compiler counts them.
+        bool second = far_second;
+        for (uint32_t k0 = 0;; k0 += kFarStep) {
+            const bool third = second && __builtin_amdgcn_ballot_w64(k0 + 2u * kFarStep < fc.count) != 0;
+            uint32_t fy[kFarStep + 1u];
+            if (third)
+                far_loads(k0 + 2u * kFarStep, fy);
 #pragma unroll
             for (uint32_t i = 0; i < kFarStep; ++i) {
                 t0 = (k0 + i == last) ? fw[i] : t0;
                 t1 = (k0 + i == last) ? fw[i + 1u] : t1;
             }
             lane_copy_step<kFarStep>(ring, fc, k0, fw);
+            if (!second)
+                break;
+#pragma unroll
+            for (uint32_t i = 0; i <= kFarStep; ++i) {
+                fw[i] = fx[i];
+                fx[i] = fy[i];
+            }
+            second = third;
         }
         lane_copy_tail(ring, fc, t0, t1);
         waiting = waiting && !far;
