@@ -648,7 +648,7 @@ def extra_workloads(args, lib, native, torch, device, local_rank, n_cu):
     # compressor makes of mesh and texture data).
     class A:
         pass
-    # "mcdf_import_spec" is the configuration as SURVEY 8(d) writes it: 64 archives of 64-512 MiB,
+    # "mcdf_import_spec" is the import configuration at its full shape: 64 archives of 64-512 MiB,
     # 50-300 files each, both kinds of content, one call; the two 8 x 256 MiB rows are kept beside
     # it (one kind of content each: the decode kernel's roofline per kind).  Each row carries the
     # import's CPU baseline: the oracle's scalar decoder + OpenSSL SHA-1, one thread and one
