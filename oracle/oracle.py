@@ -387,17 +387,17 @@ def update_snapshot(snapshot_dir: str, source_actor: str, replacements, glamoure
     if os.path.exists(info_path):                    # :431-435
         old = json.load(open(info_path, encoding="utf-8-sig"))
         info["FormatVersion"] = _ci_get(old, "FormatVersion", 1)
-        info["SourceActor"] = _ci_get(old, "SourceActor", "") or ""
+        info["SourceActor"] = _ci_get(old, "SourceActor", "")   # a JSON null stays null (Newtonsoft assigns it)
         for k, v in (_ci_get(old, "FileReplacements", {}) or {}).items():
             _ignore_case_set(folded, k, v)
     glam = {"Entries": []}
     if os.path.exists(glam_path):
         for e in (_ci_get(json.load(open(glam_path, encoding="utf-8-sig")), "Entries", []) or []):
-            glam["Entries"].append({k: _ci_get(e, k, "") or "" for k in ("Timestamp", "Description", "GlamourerString")})
+            glam["Entries"].append({k: _ci_get(e, k, "") for k in ("Timestamp", "Description", "GlamourerString")})
     cust = {"Entries": []}
     if os.path.exists(cust_path):
         for e in (_ci_get(json.load(open(cust_path, encoding="utf-8-sig")), "Entries", []) or []):
-            cust["Entries"].append({k: _ci_get(e, k, "") or ""
+            cust["Entries"].append({k: _ci_get(e, k, "")
                                     for k in ("Timestamp", "Description", "CustomizeData", "CustomizeTemplate")})
     for game_path, h in new_replacements.items():    # :453-475
         _ignore_case_set(folded, game_path, h)

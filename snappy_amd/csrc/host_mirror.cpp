@@ -216,12 +216,12 @@ std::string local_now_compact()  // DateTime.Now:yyyyMMddHHmmss
 }
 
 // SnapshotInfo (Snappy/Models/SnapshotInfo.cs:6-14) as JsonConvert writes it with Formatting.Indented.
-std::string snapshot_info_json(const std::string &format_version, const std::string &source_actor,
+std::string snapshot_info_json(const std::string &format_version, const std::string &source_actor_json,
                                const std::string &last_update, const IgnoreCaseMap &replacements,
                                const std::string &manipulation)
 {
     std::string o = "{\n  \"FormatVersion\": " + format_version + ",\n  \"SourceActor\": " +
-                    json_string(source_actor) +
+                    source_actor_json +
                     ",\n  \"LastUpdate\": " + json_string(last_update) + ",\n  \"FileReplacements\": {";
     const auto &items = replacements.items();
     for (size_t i = 0; i < items.size(); ++i) {
@@ -233,7 +233,19 @@ std::string snapshot_info_json(const std::string &format_version, const std::str
     return o;
 }
 
-std::string history_json(const std::vector<std::vector<std::pair<std::string, std::string>>> &entries)
+// A string property as Newtonsoft holds it: a JSON null read from a file is assigned to the
+// property as null and written back as null (absent properties keep the class's default "").
+struct JsonText {
+    std::string text;
+    bool is_null = false;
+    JsonText() = default;
+    JsonText(std::string s) : text(std::move(s)) {}
+    JsonText(const char *s) : text(s) {}
+    bool differs_from(const std::string &other) const { return is_null || text != other; }
+    std::string json() const { return is_null ? "null" : json_string(text); }
+};
+
+std::string history_json(const std::vector<std::vector<std::pair<std::string, JsonText>>> &entries)
 {
     if (entries.empty())
         return "{\n  \"Entries\": []\n}";
@@ -242,7 +254,7 @@ std::string history_json(const std::vector<std::vector<std::pair<std::string, st
         o += (e ? ",\n    {" : "\n    {");
         for (size_t k = 0; k < entries[e].size(); ++k) {
             o += (k ? ",\n      " : "\n      ");
-            o += json_string(entries[e][k].first) + ": " + json_string(entries[e][k].second);
+            o += json_string(entries[e][k].first) + ": " + entries[e][k].second.json();
         }
         o += "\n    }";
     }
@@ -788,19 +800,25 @@ bool read_text_file(const fs::path &path, std::string &out)
 }
 
 // A string property of a deserialized object: absent keeps the default (""), a JSON
-// null becomes "" as well (the class's strings are never written as null here).
-bool string_field(const JsonValue &obj, const char *name, std::string &out)
+// null is assigned as null.
+bool string_field(const JsonValue &obj, const char *name, JsonText &out)
 {
     const JsonValue *v = json_member(obj, name);
-    if (!v || v->kind == JsonValue::Null)
+    if (!v)
         return true;
+    if (v->kind == JsonValue::Null) {
+        out.text.clear();
+        out.is_null = true;
+        return true;
+    }
     if (v->kind != JsonValue::String)
         return false;
-    out = v->text;
+    out.text = v->text;
+    out.is_null = false;
     return true;
 }
 
-using HistoryEntries = std::vector<std::vector<std::pair<std::string, std::string>>>;
+using HistoryEntries = std::vector<std::vector<std::pair<std::string, JsonText>>>;
 
 // GlamourerHistory / CustomizeHistory as JsonConvert.DeserializeObject reads them
 // (Snappy/Models/GlamourerHistory.cs, CustomizeHistory.cs): {"Entries":[{...}]},
@@ -820,9 +838,9 @@ bool load_history(const fs::path &path, const std::vector<const char *> &fields,
     for (const JsonValue &e : entries->items) {
         if (e.kind != JsonValue::Object)
             return false;
-        std::vector<std::pair<std::string, std::string>> entry;
+        std::vector<std::pair<std::string, JsonText>> entry;
         for (const char *f : fields) {
-            std::string v;
+            JsonText v;
             if (!string_field(e, f, v))
                 return false;
             entry.emplace_back(f, v);
@@ -909,8 +927,8 @@ extern "C" int snappy_update_snapshot(const char *snapshot_dir, const char *sour
         const fs::path info_path = snapshot / "snapshot.json";
         const fs::path glam_path = snapshot / "glamourer_history.json";
         const fs::path cust_path = snapshot / "customize_history.json";
-        std::string format_version = "1", actor = source_actor ? source_actor : "";
-        std::string old_manipulation;
+        std::string format_version = "1";
+        JsonText actor(source_actor ? source_actor : ""), old_manipulation;
         IgnoreCaseMap replacements;  // SnapshotInfo.FileReplacements: OrdinalIgnoreCase
         if (fs::exists(info_path, ec)) {
             std::string text;
@@ -927,8 +945,8 @@ extern "C" int snappy_update_snapshot(const char *snapshot_dir, const char *sour
                 }
                 format_version = v->text;
             }
-            actor.clear();
-            std::string ignored;
+            actor = JsonText();
+            JsonText ignored;
             bool ok = string_field(root, "SourceActor", actor) && string_field(root, "LastUpdate", ignored) &&
                       string_field(root, "ManipulationString", old_manipulation);
             if (const JsonValue *fr = json_member(root, "FileReplacements")) {
@@ -984,7 +1002,7 @@ extern "C" int snappy_update_snapshot(const char *snapshot_dir, const char *sour
         // value differs from the last one), the time stamp.
         const std::string glamourer_now = glamourer ? glamourer : "";
         const std::string customize_now = customize ? customize : "";
-        auto last_value = [](const HistoryEntries &h, const char *field) -> const std::string * {
+        auto last_value = [](const HistoryEntries &h, const char *field) -> const JsonText * {
             if (h.empty())
                 return nullptr;
             for (const auto &kv : h.back())
@@ -992,20 +1010,20 @@ extern "C" int snappy_update_snapshot(const char *snapshot_dir, const char *sour
                     return &kv.second;
             return nullptr;
         };
-        const std::string *last_glam = last_value(glam, "GlamourerString");
-        if (!last_glam || *last_glam != glamourer_now)
-            glam.push_back({{"Timestamp", utc_now_roundtrip()},
-                            {"Description", "Glamourer Update - " + utc_now_plain() + " UTC"},
-                            {"GlamourerString", glamourer_now}});
+        const JsonText *last_glam = last_value(glam, "GlamourerString");
+        if (!last_glam || last_glam->differs_from(glamourer_now))
+            glam.push_back({{"Timestamp", JsonText(utc_now_roundtrip())},
+                            {"Description", JsonText("Glamourer Update - " + utc_now_plain() + " UTC")},
+                            {"GlamourerString", JsonText(glamourer_now)}});
         const std::string b64 = customize_now.empty() ? "" : base64_of(customize_now);
-        const std::string *last_cust = last_value(cust, "CustomizeData");
-        if ((!last_cust || *last_cust != b64) && !b64.empty())
+        const JsonText *last_cust = last_value(cust, "CustomizeData");
+        if ((!last_cust || last_cust->differs_from(b64)) && !b64.empty())
             // CustomizeTemplate stays empty: see snappy_mcdf_import_to_dir.
-            cust.push_back({{"Timestamp", utc_now_roundtrip()},
-                            {"Description", "Customize+ Update - " + utc_now_plain() + " UTC"},
-                            {"CustomizeData", b64}, {"CustomizeTemplate", ""}});
+            cust.push_back({{"Timestamp", JsonText(utc_now_roundtrip())},
+                            {"Description", JsonText("Customize+ Update - " + utc_now_plain() + " UTC")},
+                            {"CustomizeData", JsonText(b64)}, {"CustomizeTemplate", JsonText("")}});
         const std::string info_json = snapshot_info_json(
-            format_version, actor, utc_now_roundtrip(), replacements, manipulation ? manipulation : "");
+            format_version, actor.json(), utc_now_roundtrip(), replacements, manipulation ? manipulation : "");
         if (!write_text(info_path.string(), info_json) || !write_text(glam_path.string(), history_json(glam)) ||
             !write_text(cust_path.string(), history_json(cust))) {
             set_error_detail("cannot write snapshot JSON under " + snapshot.string());
@@ -1176,11 +1194,10 @@ extern "C" int snappy_mcdf_import_to_dir(const char *mcdf_path, const char *work
         // SaveSnapshotToDisk (SnapshotManager.cs:672-695).
         const std::string stamp = utc_now_roundtrip();
         const std::string info_json =
-            snapshot_info_json("1", name, stamp, game_path_to_hash, info.manipulation_data);
-        std::vector<std::vector<std::pair<std::string, std::string>>> glam = {
-            {{"Timestamp", stamp}, {"Description", "Imported from MCDF"},
-             {"GlamourerString", info.glamourer_data}}};
-        std::vector<std::vector<std::pair<std::string, std::string>>> cust;
+            snapshot_info_json("1", json_string(name), stamp, game_path_to_hash, info.manipulation_data);
+        HistoryEntries glam = {{{"Timestamp", JsonText(stamp)}, {"Description", JsonText("Imported from MCDF")},
+                                {"GlamourerString", JsonText(info.glamourer_data)}}};
+        HistoryEntries cust;
         // Convert.FromBase64String throws on malformed data (McdfManager.cs:136), after the
         // files have been extracted and before anything is saved: the import fails there.
         if (!info.customize_plus_data.empty() && !is_dotnet_base64(info.customize_plus_data)) {
@@ -1193,8 +1210,8 @@ extern "C" int snappy_mcdf_import_to_dir(const char *mcdf_path, const char *work
             // encoder and on Newtonsoft's float formatting, so no byte-exact mirror exists;
             // CustomizeHistoryEntry leaves it empty itself whenever generation fails
             // (Snappy/Models/CustomizeHistory.cs:34-48).
-            cust.push_back({{"Timestamp", stamp}, {"Description", "Imported from MCDF"},
-                            {"CustomizeData", info.customize_plus_data}, {"CustomizeTemplate", ""}});
+            cust.push_back({{"Timestamp", JsonText(stamp)}, {"Description", JsonText("Imported from MCDF")},
+                            {"CustomizeData", JsonText(info.customize_plus_data)}, {"CustomizeTemplate", JsonText("")}});
         if (!write_text((snapshot / "snapshot.json").string(), info_json) ||
             !write_text((snapshot / "glamourer_history.json").string(), history_json(glam)) ||
             !write_text((snapshot / "customize_history.json").string(), history_json(cust))) {

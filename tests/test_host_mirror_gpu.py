@@ -245,6 +245,40 @@ def _folder_state(path):
     return sorted(os.listdir(path)), files, docs
 
 
+def test_update_snapshot_keeps_json_nulls(snappy, oracle, tmp_path):
+    """String properties that are null in the files of an existing snapshot (hand-edited, or written
+    by another tool) are assigned as null by JsonConvert and written back as null; a null last
+    GlamourerString differs from any new string, so an entry is added."""
+    mods = tmp_path / "mods"
+    mods.mkdir()
+    (mods / "a.tex").write_bytes(H.random_bytes(5000, 1))
+    for root in ("ours", "theirs"):
+        d = tmp_path / root / "Hero"
+        (d / "_files").mkdir(parents=True)
+        (d / "snapshot.json").write_text(json.dumps({"FormatVersion": 1, "SourceActor": None, "LastUpdate": None,
+                                                     "FileReplacements": {"chara/old.tex": "AB" * 20},
+                                                     "ManipulationString": None}))
+        (d / "glamourer_history.json").write_text(json.dumps({"Entries": [
+            {"Timestamp": "t0", "Description": None, "GlamourerString": None}]}))
+        (d / "customize_history.json").write_text(json.dumps({"Entries": [
+            {"Timestamp": None, "Description": "d", "CustomizeData": None}]}))
+    ours, theirs = tmp_path / "ours" / "Hero", tmp_path / "theirs" / "Hero"
+    replacements = [(str(mods / "a.tex"), ["chara/a.tex"])]
+    snappy.update_snapshot(str(ours), "Hero", replacements, "", '{"Bones":{}}', "m")
+    oracle.update_snapshot(str(theirs), "Hero", replacements, "", '{"Bones":{}}', "m")
+    a, b = _folder_state(str(ours)), _folder_state(str(theirs))
+    assert a[0] == b[0] and a[1] == b[1]
+    for name in a[2]:
+        assert a[2][name] == b[2][name], name
+    info = json.load(open(ours / "snapshot.json"))
+    assert info["SourceActor"] is None and info["ManipulationString"] == "m"
+    glam = json.load(open(ours / "glamourer_history.json"))["Entries"]
+    assert len(glam) == 2 and glam[0]["GlamourerString"] is None and glam[0]["Description"] is None
+    cust = json.load(open(ours / "customize_history.json"))["Entries"]
+    assert len(cust) == 2 and cust[0]["CustomizeData"] is None and cust[0]["Timestamp"] is None
+    assert cust[0]["CustomizeTemplate"] == ""          # absent in the file: the class's default
+
+
 def test_update_snapshot_matches_the_reference_loop(snappy, oracle, tmp_path):
     """Save, then save again over the same folder: the folder the library leaves must equal,
     file for file and byte for byte (time stamps aside), the one the oracle's sequential
