@@ -1,6 +1,11 @@
+"""The one-lane SHA-1 path (one file per lane, 64 per wave) on files of 4-10 MB: how much does it
+matter where the 64 files of a wave lie in memory?  Every file is forced onto the one-lane path; the
+same sizes are laid out shuffled (a wave's files, neighbours in size order, scattered over the
+buffer) and sorted by size (a wave's files side by side).  Prints the kernel time and the ns per
+block of the largest file's chain.  Usage: python tools/probe_one_lane_big.py"""
 import os, sys
 import numpy as np
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, bench
 from snappy_amd import native
 lib = native.lib(); native.check(lib.snappy_init(0), "init"); lib.snappy_profile_enable(1)
