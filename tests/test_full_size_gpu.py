@@ -2,9 +2,14 @@
   * 10^6 files of 4-32 KB: a 3000-file sample against hashlib, and order independence (the same
     files handed over in reverse order give the same digests, un-permuted);
   * a 66 MB file's digest does not depend on the execution path or on what else is in the batch;
-  * 1 GiB of asset-like data: compress on the GPU, decode on the GPU, byte-identical."""
+  * 1 GiB of asset-like data: compress on the GPU, decode on the GPU, byte-identical;
+  * a batch import at the import configuration's own shape (64 archives of 64-512 MiB, 50-300 files
+    each, long-run and short-sequence content alternating): EVERY file's digest against hashlib."""
 import hashlib
+import json
 import os
+import struct
+from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 import pytest
@@ -77,3 +82,41 @@ def test_gib_compress_decompress_roundtrip(snappy):
     assert len(stream) < data.size
     back = np.frombuffer(snappy.lz4net_decode(stream), dtype=np.uint8)
     assert back.size == data.size and np.array_equal(back, data)
+
+
+def test_import_batch_at_the_configurations_shape(snappy):
+    import bench
+
+    rng = np.random.default_rng(0x35)
+    pools = {"asset": bench.asset_like_bytes(513 << 20, rng), "dense": bench.dense_bytes(513 << 20, rng)}
+    streams, jobs, all_lengths = [], [], []
+    with ThreadPoolExecutor(8) as pool:   # hashlib lets go of the interpreter lock on large buffers
+        for a in range(64):
+            size = int(rng.integers(64 << 20, (512 << 20) + 1))
+            kind = "asset" if a % 2 == 0 else "dense"
+            start = int(rng.integers(0, pools[kind].size - size + 1))
+            body = pools[kind][start:start + size]
+            stream, _, payload = bench.make_mcdf_archive(size, int(rng.integers(50, 301)), rng, f"full{a}", kind, body=body)
+            json_len = struct.unpack_from("<i", payload[5:9].tobytes())[0]
+            lengths = [f["Length"] for f in json.loads(payload[9:9 + json_len].tobytes())["Files"]]
+            del payload
+            assert sum(lengths) == size
+            streams.append(stream)
+            at = 0
+            all_lengths += lengths
+            for n in lengths:
+                jobs.append(pool.submit(lambda b=body[at:at + n]: hashlib.sha1(b).digest()))
+                at += n
+        got = snappy.mcdf_decode_and_hash_batch(streams, n_files_cap=len(jobs))
+        want = [j.result() for j in jobs]
+    at = 0
+    for a, r in enumerate(got):
+        assert r["status"] == 0, a
+        k = len(r["digests"])
+        for i in range(k):
+            if all_lengths[at + i] == 0:      # the importer skips empty files without hashing them
+                assert r["statuses"][i] == 1, (a, i)
+            else:
+                assert r["statuses"][i] == 0 and r["digests"][i].tobytes() == want[at + i], (a, i)
+        at += k
+    assert at == len(want)
