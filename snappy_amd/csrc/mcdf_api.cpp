@@ -370,10 +370,6 @@ int import_batch_overlapped(SlotLease &lease, std::vector<StreamJob> &jobs, std:
         SNAPPY_HIP_TRY(hipEventCreate(&e));
         marks.push_back(e);
     }
-    uint64_t largest_stream = 0;
-    for (size_t a : order)
-        largest_stream = std::max<uint64_t>(largest_stream, jobs[a].in_len);
-    (void)largest_stream;
     if ((st = reserve_transfer_ring(s, kTransferSliceBytes, 2 * order.size() + stream_bytes / kTransferSliceBytes + 1)) != SNAPPY_OK)
         return st;
     if (n_files) {

@@ -28,6 +28,18 @@ hipError_t transfer_direct(Slot &s, const std::vector<Piece> &pieces, uint64_t s
     hipError_t e = hipSuccess;
     uint64_t next_mark = 1;  // slice whose end has not been marked yet
     size_t group = 0;
+    // Fires the hook of every group whose pieces all lie before `sent` (groups without pieces included).
+    auto groups_done_through = [&](size_t sent) -> hipError_t {
+        while (group_begin && after_group && group < group_begin->size()) {
+            const size_t group_end = group + 1 < group_begin->size() ? (*group_begin)[group + 1] : pieces.size();
+            if (group_end > sent)
+                break;
+            const hipError_t he = (*after_group)(group++);
+            if (he != hipSuccess)
+                return he;
+        }
+        return hipSuccess;
+    };
     for (size_t ci = 0; ci < pieces.size(); ++ci) {
         const Piece &c = pieces[ci];
         uint64_t done = 0;
@@ -50,15 +62,11 @@ hipError_t transfer_direct(Slot &s, const std::vector<Piece> &pieces, uint64_t s
         }
         if (e != hipSuccess)
             return e;
-        if (group_begin && after_group) {
-            const size_t group_end = group + 1 < group_begin->size() ? (*group_begin)[group + 1] : pieces.size();
-            if (ci + 1 == group_end) {
-                if ((e = (*after_group)(group)) != hipSuccess)
-                    return e;
-                ++group;
-            }
-        }
+        if ((e = groups_done_through(ci + 1)) != hipSuccess)
+            return e;
     }
+    if ((e = groups_done_through(pieces.size())) != hipSuccess)   // a batch without pieces still has its groups
+        return e;
     if (!d_progress)
         return hipSuccess;
     // The last, partial slice (and any gap slices before it).

@@ -442,3 +442,46 @@ def test_mcdf_import_overlapped_path(snappy, oracle, monkeypatch):
     long_header = oracle.lz4net_encode(oracle.build_mcdf_payload("many", many), chunk_size=4096)
     batch = [good[0], long_header]
     check(snappy.mcdf_decode_and_hash_batch(batch), batch)
+
+
+def test_mcdf_import_from_page_locked_and_pageable_streams(snappy, oracle, monkeypatch):
+    """The overlapped import (forced on for a batch this small), above the size from which ordinary memory goes through the staging ring (8 MiB of
+    streams), once from ordinary memory and once from snappy_host_alloc memory (direct DMA, no
+    ring): same results, equal to the oracle's, archive by archive - an empty stream and a
+    truncated one among them."""
+    import ctypes
+
+    from snappy_amd.crypto import digests_to_hex
+
+    good = [_make_archive(oracle, 30 + 7 * k, 500 + k, chunk=1 << 20)[0] for k in range(4)]
+    streams = [good[0], b"", good[1], good[2][:-5], good[3]]
+    assert sum(len(s) for s in streams) > (8 << 20)
+    monkeypatch.setenv("SNAPPY_OVERLAP_MIN_BYTES", "0")
+    pageable = snappy.mcdf_decode_and_hash_batch(streams)
+    L = snappy.native.lib()
+    total = sum(len(s) for s in streams)
+    ptr = ctypes.c_void_p()
+    assert L.snappy_host_alloc(total + 64, ctypes.byref(ptr)) == 0
+    try:
+        pinned = np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(ctypes.c_uint8)), shape=(total + 64,))
+        views, at = [], 0
+        for s in streams:
+            pinned[at: at + len(s)] = np.frombuffer(s, dtype=np.uint8)
+            views.append(pinned[at: at + len(s)])
+            at += len(s)
+        locked = snappy.mcdf_decode_and_hash_batch(views)
+        del views, pinned
+    finally:
+        assert L.snappy_host_free(ptr) == 0
+    for s, a, b in zip(streams, pageable, locked):
+        try:
+            ref, want = oracle.mcdf_import(s), 0
+        except oracle.McdfError as e:
+            ref, want = None, e.code
+        assert a["status"] == b["status"] == want
+        assert np.array_equal(a["digests"], b["digests"]) and list(a["statuses"]) == list(b["statuses"])
+        if ref is not None:
+            assert list(a["statuses"]) == ref["statuses"]
+            for (paths, _), st_, h in zip(ref["data"]["Files"], ref["statuses"], digests_to_hex(a["digests"])):
+                if st_ == oracle.FILE_HASHED and paths:
+                    assert h in ref["blobs"]
