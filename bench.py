@@ -105,11 +105,12 @@ def make_sizes(workload: str, rng: np.random.Generator, scale: float):
 
 
 def is_strong(args, world):
-    """One corpus for the whole job whatever the number of ranks (sharded by file over them), or
-    one per rank."""
+    """One corpus for the whole job whatever the number of ranks (sharded by file over them: --strong),
+    or one per rank (the default: files are independent, so a GPU's work does not depend on how many
+    GPUs there are; with N > 1 the line also carries the one-corpus-over-N-ranks measurement)."""
     if args.weak:
         return False
-    return args.strong or args.workload == "corpus"
+    return bool(args.strong)
 
 
 def shard_lpt(lib, lengths, k):
@@ -854,8 +855,18 @@ def dry_run(args, rank, world):
         tot = torch.tensor([job_bytes, job_files], dtype=torch.float64)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         job_bytes, job_files = float(tot[0].item()), float(tot[1].item())
+    sharded = None
+    if world > 1 and not is_strong(small, world) and small.workload == "corpus":
+        # main()'s second measurement with several ranks: one corpus dealt out over them.
+        whole = make_sizes("corpus", np.random.default_rng(CORPUS_SEED), small.scale)
+        shard_of, _ = shard_lpt(native.lib(), whole, world)
+        mine = whole[shard_of == rank]
+        tot = torch.tensor([float(mine.sum()), float(len(mine))], dtype=torch.float64)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        sharded = {"job_bytes": float(tot[0].item()), "job_files": float(tot[1].item()),
+                   "corpus_bytes": float(whole.sum()), "corpus_files": float(len(whole))}
     if rank == 0:
-        print(json.dumps({"dry_run": True, "n_gpus": world, "steps": args.steps,
+        print(json.dumps({"dry_run": True, "n_gpus": world, "steps": args.steps, "one_corpus_sharded": sharded,
                           "scaling": "strong" if is_strong(small, world) else "weak",
                           "value": job_bytes * args.steps / elapsed / GB, "unit": "GB/s",
                           "job_bytes": job_bytes, "job_files": job_files, "corpus_bytes": corpus_bytes,
@@ -908,10 +919,10 @@ def main():
                     help="mcdf workload: only the decode kernel, all archives' chunks in one launch (counter passes)")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink or grow the corpus")
     ap.add_argument("--strong", action="store_true",
-                    help="one corpus for the whole job, sharded by file over the ranks (the default for the "
-                         "corpus workload)")
+                    help="one corpus for the whole job, sharded by file over the ranks, as the timed workload")
     ap.add_argument("--weak", action="store_true",
-                    help="every rank hashes a corpus of its own (the default for the other workloads)")
+                    help="every rank hashes a corpus of its own (the default; with N > 1 ranks the corpus workload "
+                         "also measures ONE corpus dealt out over the ranks and reports it beside the value)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-dry-run", action="store_true",
                     help="no GPU: exercise the multi-rank plumbing with hashlib standing in for the "
@@ -1013,6 +1024,29 @@ def main():
         per_rank = [r.tolist() for r in rows]
     job_bytes = float(sum(r[0] for r in per_rank))
 
+    # With several ranks: ONE corpus of the same kind dealt out by file over the ranks (each rank's
+    # share read out of the data it already holds; SHA-1 timing does not depend on content).
+    sharded = None
+    e2e_offsets, e2e_lengths, e2e_bytes, e2e_digests = offsets, lengths, total_bytes, digests
+    if dist is not None and not strong and args.workload == "corpus" and not args.no_extra:
+        whole = make_sizes(args.workload, np.random.default_rng(CORPUS_SEED), args.scale)
+        shard_of, _ = shard_lpt(lib, whole, world)
+        s_len = whole[shard_of == rank]
+        s_off = np.concatenate([[0], np.cumsum(s_len)[:-1]]).astype(np.uint64)
+        assert int(s_len.sum()) <= total_bytes, "a rank's share of one corpus is smaller than a corpus"
+        s_elapsed, s_kernel_ms, s_digests = hash_resident(lib, native, torch, device, local_rank, buf, s_off, s_len,
+                                                          min(args.steps, 3), 1, False, barrier)
+        t = torch.tensor([s_elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        rows = [torch.zeros(4, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(rows, torch.tensor([float(s_len.sum()), float(len(s_len)), float(np.mean(s_kernel_ms)),
+                                            float(s_len.max()) if len(s_len) else 0.0], dtype=torch.float64))
+        sharded = {"elapsed": float(t.item()), "steps": min(args.steps, 3), "rows": [r.tolist() for r in rows],
+                   "corpus_bytes": int(whole.sum())}
+        # The end-to-end leg runs on this share: the host copies of all ranks together are one corpus.
+        e2e_offsets, e2e_lengths, e2e_bytes, e2e_digests = s_off, s_len, int(s_len.sum()), s_digests
+        log(f"one corpus over {world} ranks: {sharded['elapsed']:.3f} s")
+
     # Bounded host sample for the CPU baseline, taken while the data is still resident.
     sample = None
     if rank == 0 and not args.no_cpu_baseline:
@@ -1023,7 +1057,7 @@ def main():
         sample = (buf[:sample_bytes].cpu().numpy(), k)
 
     e2e = None
-    run_e2e = not args.no_e2e and total_bytes <= args.e2e_max_gb * GB
+    run_e2e = not args.no_e2e and e2e_bytes <= args.e2e_max_gb * GB
     if dist is not None:   # every rank or none: the leg has barriers of its own
         flag = torch.tensor([1.0 if run_e2e else 0.0], dtype=torch.float64)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
@@ -1032,7 +1066,7 @@ def main():
     if run_e2e:
         holder = {"buf": buf}
         del buf
-        e2e = end_to_end(lib, native, torch, holder, offsets, lengths, total_bytes, digests, dist,
+        e2e = end_to_end(lib, native, torch, holder, e2e_offsets, e2e_lengths, e2e_bytes, e2e_digests, dist,
                          pageable=False, free_resident=True)
     else:
         del buf
@@ -1072,21 +1106,39 @@ def main():
             "kernel_ms_per_gpu": [r[2] for r in per_rank],
             "kernel_ms_each_step_rank0": [round(float(x), 3) for x in kernel_ms],
             "parallelism": (f"one corpus dealt out by file over {world} GPU(s), longest first by padded blocks "
-                            "(snappy_plan_shards_lpt)" if strong or world == 1 else
-                            f"a corpus of its own on each of {world} GPUs") + "; host dispatch, no collective",
+                            "(snappy_plan_shards_lpt)" if strong else
+                            "the whole corpus on one GPU" if world == 1 else
+                            f"a corpus of its own on each of {world} GPUs: files are independent, every GPU's "
+                            "batch is hashed where it lies") + "; host dispatch, no collective",
         },
         "kernel_only": {
             "value": value, "unit": "GB/s", "ms": ms_per_step,
-            "note": "bounded below by the serial SHA-1 chain of the largest file on any GPU (about "
-                    f"{max(r[3] for r in per_rank) / 1e6:.1f} MB here): adding GPUs does not shorten that chain, "
-                    "so the kernel-only curve is flat by construction once a GPU's share of the work fits "
-                    "under it; the end-to-end figure, bound by PCIe, is the one that scales with GPUs"},
+            "note": "a GPU's time is bounded below by the serial SHA-1 chain of its largest file (about "
+                    f"{max(r[3] for r in per_rank) / 1e6:.1f} MB here): more files per GPU cost nothing until the "
+                    "SIMDs are full, and more GPUs do not shorten a chain"},
         "roofline": sha1_roofline(algo_bytes, k_ms, max_blocks, n_cu, plan, measured_traffic(args.workload, args.scale)),
     }
+    e2e_job_bytes = job_bytes
+    if sharded is not None:
+        # Configuration 4 as it is written: one corpus sharded by file over the ranks.
+        rows = sharded["rows"]
+        e2e_job_bytes = float(sum(r[0] for r in rows))
+        out["one_corpus_sharded"] = {
+            "workload": WORKLOAD_TEXT["corpus"].format(per="job", gb=sharded["corpus_bytes"] / GB) +
+                        f", dealt out by file over {world} GPUs, longest first by padded blocks (snappy_plan_shards_lpt)",
+            "scaling": "strong",
+            "value": e2e_job_bytes * sharded["steps"] / sharded["elapsed"] / GB, "unit": "GB/s",
+            "steps": sharded["steps"], "ms_per_step": sharded["elapsed"] / sharded["steps"] * 1e3,
+            "files_per_gpu": [int(r[1]) for r in rows], "bytes_per_gpu": [int(r[0]) for r in rows],
+            "largest_file_bytes_per_gpu": [int(r[3]) for r in rows], "kernel_ms_per_gpu": [r[2] for r in rows],
+            "note": "flat in the number of GPUs by construction: one GPU already finishes the whole corpus in the "
+                    "time of its largest file's chain, every share holds a file of about that size, and more GPUs do "
+                    "not shorten a chain; end to end (below, bound by PCIe per GPU) is what shrinks with N"}
     if e2e is not None:
         bw = h2d_bandwidth(torch, device)
-        out["end_to_end"] = {
-            "value": job_bytes / e2e["seconds"] / GB, "unit": "GB/s",
+        e2e_rows = sharded["rows"] if sharded is not None else per_rank
+        (out["one_corpus_sharded"] if sharded is not None else out)["end_to_end"] = {
+            "value": e2e_job_bytes / e2e["seconds"] / GB, "unit": "GB/s",
             "ms": e2e["seconds"] * 1e3,
             "path": ("page-locked host shard (whole, no ring)" if locked else
                      "host shard in ordinary memory (more than a process may page-lock here), moved through the "
@@ -1095,8 +1147,8 @@ def main():
                       "slowest GPU's time counts",
             "host_memory_page_locked": locked,
             "h2d_pinned_GBps_measured": bw,
-            "frac_of_h2d": job_bytes / e2e["seconds"] / GB / (bw * world),
-            "copy_only_ms_at_that_rate": max(r[0] for r in per_rank) / bw / GB * 1e3,
+            "frac_of_h2d": e2e_job_bytes / e2e["seconds"] / GB / (bw * world),
+            "copy_only_ms_at_that_rate": max(r[0] for r in e2e_rows) / bw / GB * 1e3,
             "digests_match_resident_run": e2e["digests_match_resident_run"]}
 
     if world == 1 and args.workload == "corpus" and args.scale == 1.0 and not args.no_extra:

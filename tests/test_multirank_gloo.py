@@ -34,15 +34,30 @@ def test_bench_two_ranks_gloo(tmp_path):
     assert one["digest0"] == d["digest0"]         # rank 0 hashes the same corpus either way
 
 
+def test_bench_two_ranks_default_workload(tmp_path):
+    """The default workload with two ranks: a corpus of its own on each rank (files are independent,
+    so the bytes add up), and beside it one corpus dealt out over the ranks, complete."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29741", os.path.join(H.ROOT, "bench.py"),
+           "--gpus", "2", "--steps", "1", "--warmup", "0", "--cpu-dry-run", "--scale", "2"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=240, cwd=H.ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["scaling"] == "weak" and d["n_gpus"] == 2 and d["corpus_bytes"] is None
+    assert d["job_bytes"] > 1.3 * d["bytes_rank0"]
+    sh = d["one_corpus_sharded"]
+    assert sh["job_bytes"] == sh["corpus_bytes"] and sh["job_files"] == sh["corpus_files"] > 0
+
+
 def test_bench_two_ranks_one_corpus(tmp_path):
-    """The default workload: ONE corpus for the job whatever the number of ranks, dealt out by file
+    """--strong: ONE corpus for the job whatever the number of ranks, dealt out by file
     (longest first by padded blocks); the ranks' bytes and files add up to it."""
     def run(n):
         cmd = [sys.executable, os.path.join(H.ROOT, "bench.py")]
         if n > 1:
             cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
                    "--master-addr", "127.0.0.1", "--master-port", "29751", os.path.join(H.ROOT, "bench.py")]
-        cmd += ["--gpus", str(n), "--steps", "1", "--warmup", "0", "--cpu-dry-run", "--scale", "2"]
+        cmd += ["--gpus", str(n), "--steps", "1", "--warmup", "0", "--cpu-dry-run", "--scale", "2", "--strong"]
         out = subprocess.run(cmd, capture_output=True, text=True, timeout=240, cwd=H.ROOT)
         assert out.returncode == 0, out.stderr[-2000:]
         return json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
