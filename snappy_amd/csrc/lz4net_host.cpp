@@ -177,12 +177,12 @@ int prepare_streams(SlotLease &lease, std::vector<StreamJob> &jobs, StreamPlan &
     const size_t rows = static_cast<size_t>(n_chunks) + extra_chunks;
     const size_t table_bytes = rows * sizeof(Lz4Chunk);
     const size_t status_bytes = rows * sizeof(uint32_t);
-    plan.queue_words = 16u * (jobs.size() + 2u);  // a launch's queue counter every 64 bytes
+    plan.queue_words = 16u * (jobs.size() + 4u);  // a launch's queue counter every 64 bytes (the import: one per arrival, at most archives + 2, and one for the first chunks)
     if ((st = s.d_chunks.ensure(std::max<size_t>(table_bytes, 256))) != SNAPPY_OK) return st;
     if ((st = s.d_status.ensure(std::max<size_t>(status_bytes, 256))) != SNAPPY_OK) return st;
     if ((st = s.d_queues.ensure(plan.queue_words * sizeof(uint32_t))) != SNAPPY_OK) return st;
     if ((st = s.h_stage.ensure(std::max<size_t>(std::max(table_bytes, status_bytes), 256) +
-                               (jobs.size() + 2u) * sizeof(uint32_t))) != SNAPPY_OK) return st;
+                               (jobs.size() + 4u) * sizeof(uint32_t))) != SNAPPY_OK) return st;
 
     hipStream_t stream = s.stream;
     Lz4Chunk *table = static_cast<Lz4Chunk *>(s.h_stage.ptr);

@@ -32,8 +32,9 @@ struct ArchiveState {
 int header_and_slices(uint8_t *arena, const StreamJob &job, size_t a, uint64_t decoded_avail, ArchiveState &as,
                       std::vector<uint8_t> &digests_out, std::vector<uint64_t> &offsets,
                       std::vector<uint64_t> &lengths, std::vector<std::pair<size_t, size_t>> &owner,
-                      bool *header_beyond_avail)
+                      bool *header_beyond_avail, const uint8_t *host_copy = nullptr, uint64_t host_len = 0)
 {
+    // host_copy (may be null): the payload's first host_len bytes, already on the host.
     const uint64_t size = job.layout.decoded_size;
     // Header: 9 bytes tell how much JSON follows.
     uint8_t head[9] = {0};
@@ -42,7 +43,9 @@ int header_and_slices(uint8_t *arena, const StreamJob &job, size_t a, uint64_t d
         *header_beyond_avail = true;
         return SNAPPY_OK;
     }
-    if (head_len)
+    if (head_len && host_copy && head_len <= host_len)
+        std::memcpy(head, host_copy, head_len);
+    else if (head_len)
         SNAPPY_HIP_TRY(hipMemcpy(head, job.d_payload, head_len, hipMemcpyDeviceToHost));
     uint64_t need = 0;
     as.status = mcdf_header_extent(head, head_len, size, &need);
@@ -52,9 +55,14 @@ int header_and_slices(uint8_t *arena, const StreamJob &job, size_t a, uint64_t d
         *header_beyond_avail = true;
         return SNAPPY_OK;
     }
-    std::vector<uint8_t> header(static_cast<size_t>(need));
-    SNAPPY_HIP_TRY(hipMemcpy(header.data(), job.d_payload, need, hipMemcpyDeviceToHost));
-    as.status = parse_mcdf_header(header.data(), need, as.info);
+    std::vector<uint8_t> header;
+    const uint8_t *text = host_copy;
+    if (!host_copy || need > host_len) {
+        header.resize(static_cast<size_t>(need));
+        SNAPPY_HIP_TRY(hipMemcpy(header.data(), job.d_payload, need, hipMemcpyDeviceToHost));
+        text = header.data();
+    }
+    as.status = parse_mcdf_header(text, need, as.info);
     if (as.status != SNAPPY_OK)
         return SNAPPY_OK;
     as.status = mcdf_slice_files(as.info.files, as.info.body_offset, size, as.slices);
@@ -120,6 +128,12 @@ int import_batch_overlapped(SlotLease &lease, std::vector<StreamJob> &jobs, std:
     *handled = false;
     Slot &s = *lease.slot;
     const size_t n = jobs.size();
+    // SNAPPY_TRACE_IMPORT=1: host-clock milestones of the overlapped import on stderr (tuning).
+    const bool trace = std::getenv("SNAPPY_TRACE_IMPORT") != nullptr;
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto since = [&] {
+        return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    };
     uint64_t stream_bytes = 0;
     for (const StreamJob &j : jobs)
         stream_bytes += j.in_len;
@@ -137,6 +151,7 @@ int import_batch_overlapped(SlotLease &lease, std::vector<StreamJob> &jobs, std:
     if (st != SNAPPY_OK)
         return st;
     *handled = true;  // from here on the batch is laid out for this path
+    const double t_laid_out = since();
     uint8_t *arena = static_cast<uint8_t *>(s.d_data.ptr);
     const int hip_device = lease.dev->hip_device;
     Lz4Chunk *d_table = static_cast<Lz4Chunk *>(s.d_chunks.ptr);
@@ -145,6 +160,7 @@ int import_batch_overlapped(SlotLease &lease, std::vector<StreamJob> &jobs, std:
 
     // 1. The first chunk of every archive: send, decode, read the headers.
     float first_chunks_ms = 0.f;  // how long one chunk of this content takes to decode
+    double t_first_sent = 0.0;
     std::vector<Lz4Chunk> firsts;
     std::vector<size_t> first_of(n, SIZE_MAX);
     std::vector<Piece> pieces;
@@ -161,12 +177,19 @@ int import_batch_overlapped(SlotLease &lease, std::vector<StreamJob> &jobs, std:
         firsts.push_back(c);
     }
     if (!firsts.empty()) {
-        SNAPPY_HIP_TRY(transfer_to_device(s, hip_device, pieces, kTransferSliceBytes, arena, nullptr, nullptr));
+        // Every piece a group of its own: slices are then cut per piece (the pieces lie all over the
+        // arena; slices over the arena's whole span were several hundred, nearly all of them empty).
+        std::vector<size_t> one_each(pieces.size());
+        for (size_t k = 0; k < one_each.size(); ++k)
+            one_each[k] = k;
+        SNAPPY_HIP_TRY(transfer_groups_to_device(s, hip_device, pieces, one_each, kTransferSliceBytes, arena,
+                                                 [](size_t) { return hipSuccess; }));
+        t_first_sent = since();
         SNAPPY_HIP_TRY(hipMemcpyAsync(d_table + plan.n_chunks, firsts.data(), firsts.size() * sizeof(Lz4Chunk),
                                       hipMemcpyHostToDevice, s.stream));
         SNAPPY_HIP_TRY(hipEventRecord(s.ev_prof[1][0], s.stream));
         SNAPPY_HIP_TRY(launch_lz4_decode(arena, plan.in_alloc, arena, d_table + plan.n_chunks,
-                                         static_cast<uint32_t>(firsts.size()), d_queue + 16u * (n + 1u),
+                                         static_cast<uint32_t>(firsts.size()), d_queue + 16u * (n + 3u),
                                          d_status + plan.n_chunks, lease.dev->n_cu, s.stream));
         SNAPPY_HIP_TRY(hipEventRecord(s.ev_prof[1][1], s.stream));
         SNAPPY_HIP_TRY(hipStreamSynchronize(s.stream));
@@ -175,10 +198,28 @@ int import_batch_overlapped(SlotLease &lease, std::vector<StreamJob> &jobs, std:
             first_chunks_ms = 0.f;
         }
     }
+    const double t_first_decoded = since();
     std::vector<uint32_t> first_status(firsts.size(), 0);
     if (!firsts.empty())
         SNAPPY_HIP_TRY(hipMemcpy(first_status.data(), d_status + plan.n_chunks, firsts.size() * sizeof(uint32_t),
                                  hipMemcpyDeviceToHost));
+    // The decoded starts of all first chunks come to the host in one go, into the page-locked ring
+    // (idle between the transfers): two small blocking copies per archive took 5 ms for 64 archives.
+    const uint8_t *prefixes = nullptr;
+    if (!firsts.empty() && firsts.size() * uint64_t(kHeaderPrefix) <= kTransferSliceBytes &&
+        reserve_transfer_ring(s, kTransferSliceBytes, 1) == SNAPPY_OK) {
+        uint8_t *ring = static_cast<uint8_t *>(s.h_ring.ptr);
+        for (size_t a = 0; a < n; ++a) {
+            if (first_of[a] == SIZE_MAX)
+                continue;
+            const uint64_t take = std::min<uint64_t>(firsts[first_of[a]].orig_len, kHeaderPrefix);
+            if (take)
+                SNAPPY_HIP_TRY(hipMemcpyAsync(ring + first_of[a] * size_t(kHeaderPrefix), jobs[a].d_payload, take,
+                                              hipMemcpyDeviceToHost, s.stream));
+        }
+        SNAPPY_HIP_TRY(hipStreamSynchronize(s.stream));
+        prefixes = ring;
+    }
     std::vector<uint64_t> offsets, lengths;
     std::vector<std::pair<size_t, size_t>> owner;  // (archive, file)
     bool header_beyond = false;
@@ -192,10 +233,17 @@ int import_batch_overlapped(SlotLease &lease, std::vector<StreamJob> &jobs, std:
             continue;
         const Lz4Chunk *fc = first_of[a] == SIZE_MAX ? nullptr : &firsts[first_of[a]];
         const uint64_t avail = !fc ? 0 : (fc->prefix_len ? fc->prefix_len : fc->orig_len);
-        st = header_and_slices(arena, jobs[a], a, avail, as, digests_out[a], offsets, lengths, owner, &header_beyond);
+        const bool on_host = prefixes && fc;
+        st = header_and_slices(arena, jobs[a], a, avail, as, digests_out[a], offsets, lengths, owner, &header_beyond,
+                               on_host ? prefixes + first_of[a] * size_t(kHeaderPrefix) : nullptr,
+                               on_host ? std::min<uint64_t>(fc->orig_len, kHeaderPrefix) : 0);
         if (st != SNAPPY_OK)
             return st;
     }
+    if (trace)
+        std::fprintf(stderr, "[import] streams laid out at %.1f ms, first chunks sent at %.1f, decoded at %.1f (kernel %.2f ms), "
+                             "headers of %zu archives parsed at %.1f ms\n",
+                     t_laid_out, t_first_sent, t_first_decoded, first_chunks_ms, n, since());
     if (header_beyond || owner.size() >= 0xFFFFFFF0ull) {
         // A header that runs past its archive's first chunk (many thousands of files):
         // the plain order of things handles it.
@@ -212,48 +260,100 @@ int import_batch_overlapped(SlotLease &lease, std::vector<StreamJob> &jobs, std:
         if (!jobs[a].dropped && jobs[a].in_len)
             order.push_back(a);
     std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) { return largest[x] > largest[y]; });
-    std::vector<uint32_t> epoch_of(n, 0);
+    // What arrives as one piece of work: a contiguous range of an archive's stream and the chunks
+    // that can be decoded once it is there.  Normally a whole archive; the first archive, which
+    // holds the batch's largest file, comes in three: the chunks that file lies in, then the
+    // stream in front of them, then the rest, so that the chain which decides the import's
+    // finishing time starts after some tens of chunks' transfer and decode instead of after a
+    // whole archive's.  SNAPPY_MCDF_NO_SPLIT=1: whole archives only (comparisons).
+    struct Arrival {
+        size_t archive;
+        Piece piece;
+        std::vector<Lz4Chunk> rows;  // arena coordinates
+    };
+    std::vector<Arrival> arrivals;
+    size_t big = SIZE_MAX;  // the largest file, as an index into owner / lengths
+    for (size_t k = 0; k < owner.size(); ++k)
+        if (big == SIZE_MAX || lengths[k] > lengths[big])
+            big = k;
+    bool big_alone = false;
+    for (size_t pos = 0; pos < order.size(); ++pos) {
+        const size_t a = order[pos];
+        const StreamJob &j = jobs[a];
+        const std::vector<Lz4Chunk> &chunks = j.layout.chunks;
+        auto rows_of = [&](size_t from, size_t to) {
+            std::vector<Lz4Chunk> rows(chunks.begin() + static_cast<ptrdiff_t>(from), chunks.begin() + static_cast<ptrdiff_t>(to));
+            for (Lz4Chunk &c : rows) {
+                c.in_off += j.in_off;
+                c.out_off += j.out_off;
+            }
+            return rows;
+        };
+        size_t c0 = 0, c1 = 0;
+        if (pos == 0 && big != SIZE_MAX && owner[big].first == a && lengths[big] > 0 &&
+            std::getenv("SNAPPY_MCDF_NO_SPLIT") == nullptr) {
+            const uint64_t lo = offsets[big] - j.out_off, hi = lo + lengths[big];  // the file's place in the payload
+            while (c0 < chunks.size() && chunks[c0].out_off + chunks[c0].orig_len <= lo)
+                ++c0;
+            c1 = c0;
+            while (c1 < chunks.size() && chunks[c1].out_off < hi)
+                ++c1;
+        }
+        if (c1 > c0 && chunks.size() - (c1 - c0) >= 4) {
+            const uint64_t from = chunks[c0].in_off, to = chunks[c1 - 1].in_off + chunks[c1 - 1].comp_len;
+            arrivals.push_back({a, {j.in + from, j.in_off + from, to - from}, rows_of(c0, c1)});
+            arrivals.push_back({a, {j.in, j.in_off, from}, rows_of(0, c0)});
+            arrivals.push_back({a, {j.in + to, j.in_off + to, j.in_len - to}, rows_of(c1, chunks.size())});
+            big_alone = true;
+        } else {
+            arrivals.push_back({a, {j.in, j.in_off, j.in_len}, rows_of(0, chunks.size())});
+        }
+    }
+    std::vector<uint32_t> epoch_of(n, 0);  // an archive is there with its last arrival
+    std::vector<size_t> arrival_archive(arrivals.size());
     uint32_t *numbers = reinterpret_cast<uint32_t *>(static_cast<uint8_t *>(s.h_stage.ptr) + s.h_stage.cap) -
-                        (n + 2u);  // page-locked words the counter is raised from
-    for (size_t k = 0; k < order.size(); ++k) {
-        epoch_of[order[k]] = static_cast<uint32_t>(k + 1);
+                        (n + 4u);  // page-locked words the counter is raised from
+    for (size_t k = 0; k < arrivals.size(); ++k) {
+        epoch_of[arrivals[k].archive] = static_cast<uint32_t>(k + 1);
+        arrival_archive[k] = arrivals[k].archive;
         numbers[k] = static_cast<uint32_t>(k + 1);
     }
     // The chunk table once more, in arrival order, so that any run of consecutive
     // arrivals can be decoded by one launch.
     std::vector<Lz4Chunk> ordered;
-    std::vector<uint64_t> first_row(order.size() + 1, 0);
-    for (size_t k = 0; k < order.size(); ++k) {
-        const StreamJob &j = jobs[order[k]];
+    std::vector<uint64_t> first_row(arrivals.size() + 1, 0);
+    for (size_t k = 0; k < arrivals.size(); ++k) {
         first_row[k] = ordered.size();
-        for (Lz4Chunk c : j.layout.chunks) {
-            c.in_off += j.in_off;
-            c.out_off += j.out_off;
-            ordered.push_back(c);
-        }
+        ordered.insert(ordered.end(), arrivals[k].rows.begin(), arrivals[k].rows.end());
     }
-    first_row[order.size()] = ordered.size();
+    first_row[arrivals.size()] = ordered.size();
     if (!ordered.empty())
         SNAPPY_HIP_TRY(hipMemcpy(d_table, ordered.data(), ordered.size() * sizeof(Lz4Chunk), hipMemcpyHostToDevice));
+    // Every file waits for its archive's last arrival; the largest file, sent ahead, for the first.
+    std::vector<uint32_t> file_epoch(owner.size());
+    for (size_t k = 0; k < owner.size(); ++k)
+        file_epoch[k] = (big_alone && k == big) ? 1u : epoch_of[owner[k].first];
 
     // The files in the order their archives arrive (stable: an archive's files keep their order).
     {
         std::vector<size_t> by_arrival(owner.size());
         for (size_t k = 0; k < by_arrival.size(); ++k)
             by_arrival[k] = k;
-        std::stable_sort(by_arrival.begin(), by_arrival.end(), [&](size_t x, size_t y) {
-            return epoch_of[owner[x].first] < epoch_of[owner[y].first];
-        });
+        std::stable_sort(by_arrival.begin(), by_arrival.end(),
+                         [&](size_t x, size_t y) { return file_epoch[x] < file_epoch[y]; });
         std::vector<uint64_t> off2(owner.size()), len2(owner.size());
         std::vector<std::pair<size_t, size_t>> own2(owner.size());
+        std::vector<uint32_t> epoch2(owner.size());
         for (size_t k = 0; k < by_arrival.size(); ++k) {
             off2[k] = offsets[by_arrival[k]];
             len2[k] = lengths[by_arrival[k]];
             own2[k] = owner[by_arrival[k]];
+            epoch2[k] = file_epoch[by_arrival[k]];
         }
         offsets.swap(off2);
         lengths.swap(len2);
         owner.swap(own2);
+        file_epoch.swap(epoch2);
     }
 
     // A chunk is decoded by one wave, and on streams of short sequences its chain of
@@ -308,7 +408,7 @@ int import_batch_overlapped(SlotLease &lease, std::vector<StreamJob> &jobs, std:
         if (!owner.empty() &&
             (st = run_sha1_tables(lease, arena, offsets.data(), lengths.data(), owner.size(), hashed.data(), nullptr)) != SNAPPY_OK)
             return st;
-        return finish_overlapped(s, jobs, states, digests_out, order, first_row, ordered.size(), owner, hashed);
+        return finish_overlapped(s, jobs, states, digests_out, arrival_archive, first_row, ordered.size(), owner, hashed);
     }
 
     // The decode launches: the first archive alone (it holds the largest file, whose SHA-1 chain
@@ -321,11 +421,11 @@ int import_batch_overlapped(SlotLease &lease, std::vector<StreamJob> &jobs, std:
         run_len = std::min<size_t>(8, static_cast<size_t>(4.f * whole_chunk_ms / (transfer_ms > 0.f ? transfer_ms : 1.f)) + 1);
     if (const char *v = std::getenv("SNAPPY_MCDF_DECODE_RUN"))  // tuning
         run_len = std::max<size_t>(1, std::strtoul(v, nullptr, 10));
-    std::vector<bool> run_end_at(order.size(), false);
+    std::vector<bool> run_end_at(arrivals.size(), false);
     {
         size_t from = 0;
-        for (size_t k = 0; k < order.size(); ++k)
-            if (k == 0 || k + 1 == order.size() || k + 1 - from >= run_len) {
+        for (size_t k = 0; k < arrivals.size(); ++k)
+            if (k == 0 || k + 1 == arrivals.size() || k + 1 - from >= run_len) {
                 run_end_at[k] = true;
                 from = k + 1;
             }
@@ -336,14 +436,14 @@ int import_batch_overlapped(SlotLease &lease, std::vector<StreamJob> &jobs, std:
     std::vector<uint32_t> group_ends;
     {
         size_t runs = 0;
-        for (size_t k = 0; k < order.size(); ++k)
+        for (size_t k = 0; k < arrivals.size(); ++k)
             runs += run_end_at[k] ? 1 : 0;
         const size_t runs_per_group = (runs + kMaxHashGroups - 1) / kMaxHashGroups;
         size_t file = 0, seen_runs = 0;
-        for (size_t k = 0; k < order.size(); ++k) {
-            while (file < owner.size() && epoch_of[owner[file].first] <= k + 1)
+        for (size_t k = 0; k < arrivals.size(); ++k) {
+            while (file < owner.size() && file_epoch[file] <= k + 1)
                 ++file;
-            if (run_end_at[k] && (++seen_runs % std::max<size_t>(1, runs_per_group) == 0 || k + 1 == order.size() || k == 0))
+            if (run_end_at[k] && (++seen_runs % std::max<size_t>(1, runs_per_group) == 0 || k + 1 == arrivals.size() || k == 0))
                 group_ends.push_back(static_cast<uint32_t>(file));
         }
         if (group_ends.empty() || group_ends.back() != owner.size())
@@ -365,12 +465,12 @@ int import_batch_overlapped(SlotLease &lease, std::vector<StreamJob> &jobs, std:
                 (void)hipEventDestroy(e);
         }
     } destroy_events{marks};
-    for (size_t k = 0; k < 3 * order.size(); ++k) {  // per archive: transfers enqueued, decode begins, decode ends
+    for (size_t k = 0; k < 3 * arrivals.size(); ++k) {  // per arrival: transfers enqueued, decode begins, decode ends
         hipEvent_t e;
         SNAPPY_HIP_TRY(hipEventCreate(&e));
         marks.push_back(e);
     }
-    if ((st = reserve_transfer_ring(s, kTransferSliceBytes, 2 * order.size() + stream_bytes / kTransferSliceBytes + 1)) != SNAPPY_OK)
+    if ((st = reserve_transfer_ring(s, kTransferSliceBytes, 2 * arrivals.size() + stream_bytes / kTransferSliceBytes + 1)) != SNAPPY_OK)
         return st;
     if (n_files) {
         // The tables, the arrival numbers and the digests share one buffer.
@@ -382,7 +482,7 @@ int import_batch_overlapped(SlotLease &lease, std::vector<StreamJob> &jobs, std:
         d_digests = reinterpret_cast<uint8_t *>(d_epochs + n_files);
         std::vector<uint32_t> epochs(n_files);
         for (size_t k = 0; k < n_files; ++k)
-            epochs[k] = epoch_of[owner[k].first];
+            epochs[k] = file_epoch[k];
         Sha1Arrival zero = {};
         // ~1 s without progress before the kernel stops waiting.  Progress here is an archive's
         // transfer and decode, tens of milliseconds; where kernels cannot run side by side (a
@@ -414,13 +514,9 @@ int import_batch_overlapped(SlotLease &lease, std::vector<StreamJob> &jobs, std:
     // largest file, whose SHA-1 chain decides when the import ends), the others in runs
     // of `run_len`, larger where a chunk takes long next to an archive's transfer.
     hipError_t failure = hipSuccess;
-    std::vector<std::pair<size_t, size_t>> launches;  // (first, last + 1) positions in `order` per decode launch
-    // SNAPPY_TRACE_IMPORT=1: host-clock milestones of the overlapped import on stderr (tuning).
-    const bool trace = std::getenv("SNAPPY_TRACE_IMPORT") != nullptr;
-    const auto t_begin = std::chrono::steady_clock::now();
-    auto since = [&] {
-        return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
-    };
+    std::vector<std::pair<size_t, size_t>> launches;  // (first, last + 1) arrivals per decode launch
+    if (trace)
+        std::fprintf(stderr, "[import] waiting kernel enqueued at %.1f ms\n", since());
     auto decode_run = [&](size_t from, size_t to) -> hipError_t {
         const uint32_t rows = static_cast<uint32_t>(first_row[to] - first_row[from]);
         // The run's last transfer has been enqueued: everything up to here on the copy stream.
@@ -449,10 +545,9 @@ int import_batch_overlapped(SlotLease &lease, std::vector<StreamJob> &jobs, std:
     {
         std::vector<Piece> in_order;
         std::vector<size_t> group_begin;
-        for (size_t k = 0; k < order.size(); ++k) {
-            const size_t a = order[k];
+        for (const Arrival &ar : arrivals) {
             group_begin.push_back(in_order.size());
-            in_order.push_back({jobs[a].in, jobs[a].in_off, jobs[a].in_len});
+            in_order.push_back(ar.piece);
         }
         size_t run_from = 0;
         const AfterGroup after_archive = [&](size_t k) -> hipError_t {
@@ -462,8 +557,9 @@ int import_batch_overlapped(SlotLease &lease, std::vector<StreamJob> &jobs, std:
                 run_from = k + 1;
             }
             if (trace)
-                std::fprintf(stderr, "[import] archive %zu (%.1f MB stream, largest file %.1f MB) handed to the copy stream at %.1f ms%s\n",
-                             k, jobs[order[k]].in_len / 1e6, largest[order[k]] / 1e6, since(), run_end_at[k] ? ", run ends" : "");
+                std::fprintf(stderr, "[import] arrival %zu (%.1f MB of archive %zu's stream, whose largest file has %.1f MB) handed to the copy stream at %.1f ms%s\n",
+                             k, arrivals[k].piece.len / 1e6, arrivals[k].archive, largest[arrivals[k].archive] / 1e6, since(),
+                             run_end_at[k] ? ", run ends" : "");
             return e;
         };
         if (!in_order.empty())
@@ -521,7 +617,7 @@ int import_batch_overlapped(SlotLease &lease, std::vector<StreamJob> &jobs, std:
         if (!launches.empty())
             profile_store(1, total_ms);
     }
-    return finish_overlapped(s, jobs, states, digests_out, order, first_row, ordered.size(), owner, packed);
+    return finish_overlapped(s, jobs, states, digests_out, arrival_archive, first_row, ordered.size(), owner, packed);
 }
 
 // Decodes all archives, parses their headers and hashes every file body.

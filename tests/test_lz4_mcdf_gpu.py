@@ -378,7 +378,9 @@ def test_mcdf_import_overlapped_path(snappy, oracle, monkeypatch):
     chunks, the SHA-1 kernel waiting for each archive's decode): forced on for small archives and
     compared with the plain order of things and with the oracle.  Includes an archive whose later
     chunk is malformed, one that is truncated, one with a bad header, an empty one, one whose first
-    chunk is stored, and a batch in which one header runs past its first chunk (handed back)."""
+    chunk is stored, and a batch in which one header runs past its first chunk (handed back).
+    The archive with the batch's largest file arrives in three parts (that file's chunks first);
+    one turn sends whole archives only."""
     from snappy_amd.crypto import digests_to_hex
 
     good = [_make_archive(oracle, 12 + 5 * k, 40 + k, chunk=1 << 16)[0] for k in range(4)]
@@ -414,12 +416,15 @@ def test_mcdf_import_overlapped_path(snappy, oracle, monkeypatch):
     plain = snappy.mcdf_decode_and_hash_batch(streams)
     check(plain, streams)
     monkeypatch.setenv("SNAPPY_OVERLAP_MIN_BYTES", "0")
-    for turn in ("waiting kernel", "waiting kernel", "one decode launch per archive", "plain order"):
+    for turn in ("waiting kernel", "waiting kernel", "one decode launch per archive", "whole archives", "plain order"):
         # Archives this small normally take the short way (send, decode, hash); with the size
         # limit at 0 they go through the overlapped import: the SHA-1 kernel waiting, the files
         # planned group by group in arrival order; the last turn sends everything first.
         monkeypatch.delenv("SNAPPY_MCDF_PLAIN_ORDER", raising=False)
         monkeypatch.delenv("SNAPPY_MCDF_DECODE_RUN", raising=False)
+        monkeypatch.delenv("SNAPPY_MCDF_NO_SPLIT", raising=False)
+        if turn == "whole archives":   # the largest file's chunks are not sent ahead of their archive
+            monkeypatch.setenv("SNAPPY_MCDF_NO_SPLIT", "1")
         if turn == "plain order":
             monkeypatch.setenv("SNAPPY_MCDF_PLAIN_ORDER", "1")
         if turn == "one decode launch per archive":
@@ -429,6 +434,7 @@ def test_mcdf_import_overlapped_path(snappy, oracle, monkeypatch):
         for a, b in zip(plain, over):
             assert a["status"] == b["status"] and np.array_equal(a["digests"], b["digests"]), turn
     monkeypatch.delenv("SNAPPY_MCDF_PLAIN_ORDER", raising=False)
+    monkeypatch.delenv("SNAPPY_MCDF_NO_SPLIT", raising=False)
     # 75 archives, one decode launch each: more runs than hashing groups (64), so groups of two runs.
     monkeypatch.setenv("SNAPPY_MCDF_DECODE_RUN", "1")
     pool = [_make_archive(oracle, 2 + k, 300 + k, chunk=1 << 15)[0] for k in range(9)] + [broken, b""]

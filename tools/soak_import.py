@@ -105,6 +105,10 @@ def main():
         else:
             os.environ.pop("SNAPPY_MCDF_PLAIN_ORDER", None)
         os.environ["SNAPPY_MCDF_DECODE_RUN"] = str(int(mode_rng.choice([1, 1, 2, 3, 8])))
+        if mode_rng.random() < 0.3:   # whole archives only: the largest file's chunks are not sent ahead
+            os.environ["SNAPPY_MCDF_NO_SPLIT"] = "1"
+        else:
+            os.environ.pop("SNAPPY_MCDF_NO_SPLIT", None)
         until = min(time.time() + 6.0, t0 + budget)
         threads = [threading.Thread(target=worker, args=(1000 * spell + s, until)) for s in (1, 2)]
         for t in threads:
