@@ -41,6 +41,20 @@ typedef __attribute__((address_space(3))) uint8_t LdsByte;  // an LDS address is
 
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 
+// A pointer that went through LDS (the pair's command slots) comes back as a generic one, and
+// the compiler then uses flat instructions for it: those count as LDS operations too, so every
+// wait for an LDS result also waits for the loads from memory in flight, and before each flat
+// load everything is drained because it might read LDS.  This says what the pointer is (device
+// memory, the same address in every lane), and the accesses become global ones again.
+template <typename T>
+__device__ __forceinline__ T *known_global(T *p)
+{
+    const uint64_t v = reinterpret_cast<uintptr_t>(p);
+    const uint64_t same = (static_cast<uint64_t>(uni(static_cast<uint32_t>(v >> 32))) << 32) | uni(static_cast<uint32_t>(v));
+    typedef __attribute__((address_space(1))) T GlobalT;
+    return (T *)(GlobalT *)same;
+}
+
 // All vector memory operations issued so far have completed (s_waitcnt vmcnt(0);
 // the other two counters are left at their maximum).
 __device__ __forceinline__ void wait_for_memory() { __builtin_amdgcn_s_waitcnt(0x0F70); }
@@ -433,6 +447,10 @@ constexpr uint32_t kBatchInput = 512;   // staged bytes a sequence may touch fro
 constexpr uint32_t kLitStep = 8;        // dwords a lane has in flight per step when copying literals
 constexpr uint32_t kMatchStep = 4;      // and matches: a match may repeat a pattern of 16 bytes or more
 constexpr uint32_t kFarStep = 10;       // and matches read from memory: 37 bytes or more per round trip
+#ifndef SNAPPY_LZ4_FAR_DEPTH
+#define SNAPPY_LZ4_FAR_DEPTH 3
+#endif
+constexpr uint32_t kFarDepth = SNAPPY_LZ4_FAR_DEPTH;  // steps of such a match in flight
 
 // A lane's copy of n bytes to output position dst of the ring, done with naturally
 // aligned LDS accesses only.  The copy is cut along the dwords of the destination:
@@ -827,30 +845,37 @@ __device__ __forceinline__ void batch_matches(uint8_t *dst, uint8_t *ring, const
     const bool far = mine && !in_ring;
     const bool any_far = !(tuning & kPhaseSwitches & 4u) && __builtin_amdgcn_ballot_w64(far) != 0;
     const uint32_t far_len = far ? ml : 0u;
-    // Dwords below this one hold nothing of the chunk's output (and may lie outside the allocation).
-    const uint32_t *floor32 = reinterpret_cast<const uint32_t *>(reinterpret_cast<uintptr_t>(dst) & ~uintptr_t(3));
-    const uintptr_t from0 = reinterpret_cast<uintptr_t>(dst) + (far ? s : 3u) - (mo & 3u);  // >= dst - 3
-    const uint32_t *from32 = reinterpret_cast<const uint32_t *>(from0 & ~uintptr_t(3));
+    // The source dwords are numbered from the dword that holds the chunk's first output byte:
+    // dwords below it hold nothing of the chunk's output (and may lie outside the allocation), so
+    // a number below 0 (only -1 occurs) is read as dword 0.  One base address, the same in every
+    // lane, and a 32-bit number per lane: the loads are global ones with a scalar base.
+    const uint32_t lead = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(dst)) & 3u;
+    const uint32_t *floor32 = reinterpret_cast<const uint32_t *>(dst - lead);
+    const int32_t from0 = static_cast<int32_t>(lead + (far ? s : 3u) - (mo & 3u));  // byte offset from floor32, >= -3
+    const int32_t from_dw = from0 >> 2;
     LaneCopy fc(mo, far_len, 0);
     fc.m = static_cast<uint32_t>(from0) & 3u;
-    // Two steps of source dwords are kept in flight: a step is 40 bytes, and one round trip after
-    // the other the steps of long matches (200 bytes: five) took more of the helper's time on
-    // such streams than everything else it does.
-    uint32_t fw[kFarStep + 1u], fx[kFarStep + 1u];
+    // Several steps of source dwords are kept in flight (a step is 40 bytes): one round trip after
+    // the other, the steps of long matches (200 bytes: five) took more of the helper's time on
+    // such streams than everything else it does.  kFarDepth register sets; the one a copy step
+    // has used up is asked for again at once, for the step kFarDepth further on.
+    uint32_t ff[kFarDepth][kFarStep + 1u];
     auto far_loads = [&](uint32_t k0, uint32_t (&to)[kFarStep + 1u]) {
 #pragma unroll
         for (uint32_t i = 0; i <= kFarStep; ++i) {
-            const uint32_t *at = from32 + (fc.wants(k0 + i) ? k0 + i : 0u);
-            to[i] = *(at < floor32 ? floor32 : at);
+            const int32_t at = from_dw + static_cast<int32_t>(fc.wants(k0 + i) ? k0 + i : 0u);
+            to[i] = floor32[at < 0 ? 0u : static_cast<uint32_t>(at)];
         }
     };
-    bool far_second = false;
-    if (any_far) {
-        far_loads(0, fw);
-        far_second = __builtin_amdgcn_ballot_w64(kFarStep < fc.count) != 0;
-        if (far_second)
-            far_loads(kFarStep, fx);
-    }
+    // Steps some lane has dwords in (uniform).
+    uint32_t far_steps = 0;
+    if (any_far)
+        while (__builtin_amdgcn_ballot_w64(far_steps * kFarStep < fc.count) != 0)
+            ++far_steps;
+#pragma unroll
+    for (uint32_t d = 0; d < kFarDepth; ++d)
+        if (d < far_steps)
+            far_loads(d * kFarStep, ff[d]);
 
     // Matches that read the ring are copied in rounds: a match is copied once every
     // match whose output it reads has been.  These are the sequences from the one that
@@ -885,28 +910,24 @@ __device__ __forceinline__ void batch_matches(uint8_t *dst, uint8_t *ring, const
         // step that holds them keeps them (a step's dwords are registers, not memory).
         uint32_t t0 = 0, t1 = 0;
         const uint32_t last = fc.count ? fc.count - 1u : 0u;
-        // fw: step k0 (wanted now), fx: step k0 + kFarStep (in flight), fy: the one after, asked
-        // for before fw is waited for.  Loads return in order and the compiler counts them.
-        bool second = far_second;
-        for (uint32_t k0 = 0;; k0 += kFarStep) {
-            const bool third = second && __builtin_amdgcn_ballot_w64(k0 + 2u * kFarStep < fc.count) != 0;
-            uint32_t fy[kFarStep + 1u];
-            if (third)
-                far_loads(k0 + 2u * kFarStep, fy);
+        // Loads return in order and the compiler counts them: the wait in front of a step is
+        // for that step's loads alone, the later sets stay in flight.
+        for (uint32_t base = 0; base < far_steps; base += kFarDepth) {
 #pragma unroll
-            for (uint32_t i = 0; i < kFarStep; ++i) {
-                t0 = (k0 + i == last) ? fw[i] : t0;
-                t1 = (k0 + i == last) ? fw[i + 1u] : t1;
-            }
-            lane_copy_step<kFarStep>(ring, fc, k0, fw);
-            if (!second)
-                break;
+            for (uint32_t d = 0; d < kFarDepth; ++d) {
+                const uint32_t step = base + d;
+                if (step < far_steps) {
+                    const uint32_t k0 = step * kFarStep;
 #pragma unroll
-            for (uint32_t i = 0; i <= kFarStep; ++i) {
-                fw[i] = fx[i];
-                fx[i] = fy[i];
+                    for (uint32_t i = 0; i < kFarStep; ++i) {
+                        t0 = (k0 + i == last) ? ff[d][i] : t0;
+                        t1 = (k0 + i == last) ? ff[d][i + 1u] : t1;
+                    }
+                    lane_copy_step<kFarStep>(ring, fc, k0, ff[d]);
+                    if (step + kFarDepth < far_steps)
+                        far_loads(k0 + kFarDepth * kFarStep, ff[d]);
+                }
             }
-            second = third;
         }
         lane_copy_tail(ring, fc, t0, t1);
         waiting = waiting && !far;
@@ -1068,12 +1089,13 @@ __device__ void helper_loop(TeamShared *sh, uint8_t *ring, uint32_t lane, uint32
             info.start = uni(sh->info[slot].start);
             info.end = uni(sh->info[slot].end);
             info.valid_from = uni(sh->info[slot].valid_from);
-            batch_matches<PairTeam>(sh->dst[slot], ring, desc, info, lane, tuning, clk);
+            batch_matches<PairTeam>(known_global(sh->dst[slot]), ring, desc, info, lane, tuning, clk);
             wait_for_memory();  // the flush is in memory before the parser is told so
         } else if (cmd == kCmdCopy) {
             const uint32_t n = uni(sh->len[slot]);
             const uint32_t half = (n >> 1) & ~15u;
-            copy_run<PairTeam::kCopyDepth>(sh->dst[slot] + half, sh->src[slot] + half, n - half, lane);
+            copy_run<PairTeam::kCopyDepth>(known_global(sh->dst[slot]) + half, known_global(sh->src[slot]) + half, n - half,
+                                           lane);
             wait_for_memory();
             __syncthreads();
         }

@@ -617,7 +617,10 @@ int import_batch_overlapped(SlotLease &lease, std::vector<StreamJob> &jobs, std:
         if (!launches.empty())
             profile_store(1, total_ms);
     }
-    return finish_overlapped(s, jobs, states, digests_out, arrival_archive, first_row, ordered.size(), owner, packed);
+    st = finish_overlapped(s, jobs, states, digests_out, arrival_archive, first_row, ordered.size(), owner, packed);
+    if (trace)
+        std::fprintf(stderr, "[import] results sorted out at %.1f ms\n", since());
+    return st;
 }
 
 // Decodes all archives, parses their headers and hashes every file body.
