@@ -97,9 +97,12 @@ int finish_overlapped(Slot &s, std::vector<StreamJob> &jobs, std::vector<Archive
                 if (chunk_status[r] != 0)
                     jobs[order[k]].status = SNAPPY_E_LZ4_CORRUPT;
     }
+    // The stream is read to its end before anything looks at the header, so a stream error comes
+    // before a header error, and among stream errors the malformed block (every decoded chunk lies
+    // before the point where the walk over the chunk headers stopped) before whatever stopped the walk.
     for (size_t a = 0; a < n; ++a)
-        if (jobs[a].status != SNAPPY_OK && states[a].status == SNAPPY_OK) {
-            states[a].status = jobs[a].status;  // a later block of the stream was malformed
+        if (jobs[a].status != SNAPPY_OK) {
+            states[a].status = jobs[a].status;
             digests_out[a].clear();
         }
     for (size_t k = 0; k < owner.size(); ++k)

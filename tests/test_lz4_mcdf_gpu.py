@@ -491,3 +491,65 @@ def test_mcdf_import_from_page_locked_and_pageable_streams(snappy, oracle, monke
             for (paths, _), st_, h in zip(ref["data"]["Files"], ref["statuses"], digests_to_hex(a["digests"])):
                 if st_ == oracle.FILE_HASHED and paths:
                     assert h in ref["blobs"]
+
+
+def _chunk_spans(stream):
+    """(header start, payload start, payload end) of every chunk of an lz4net stream."""
+    def varint(at):
+        v, shift = 0, 0
+        while True:
+            b = stream[at]
+            at += 1
+            v |= (b & 0x7F) << shift
+            shift += 7
+            if not b & 0x80:
+                return v, at
+    spans, at = [], 0
+    while at < len(stream):
+        start = at
+        flags, at = varint(at)
+        n, at = varint(at)
+        if flags & 1:
+            n, at = varint(at)
+        spans.append((start, at, at + n))
+        at += n
+    return spans
+
+
+def test_malformed_block_comes_before_a_later_bad_chunk_header(snappy, oracle, monkeypatch):
+    """Damage inside one chunk's payload and in the next chunk's header: the block
+    fails to decode AND the walk over the chunk headers stops right behind it.  The reference's
+    CopyTo decodes chunk by chunk, so it meets the malformed block first; the batch import says the
+    same in the overlapped order, in the plain order and through the single-archive call."""
+    stream, _ = _make_archive(oracle, 25, 77, chunk=1 << 16)
+    spans = _chunk_spans(stream)
+    # a compressed chunk (its flags byte has bit 0 set) with another chunk behind it
+    k = next(i for i in range(1, len(spans) - 1) if stream[spans[i][0]] & 1 and spans[i][2] - spans[i][1] > 64)
+    end = spans[k][2]
+    assert end == spans[k + 1][0]
+    # A byte of the chunk whose flipping makes the block malformed (most bytes are literals).
+    for at in range(spans[k][1], spans[k][2]):
+        bad = bytearray(stream)
+        bad[at] ^= 0xFF
+        if oracle.lz4net_decode(bytes(bad))[0] == snappy.native.E_LZ4_CORRUPT:
+            break
+    else:
+        pytest.fail("no byte of the chunk breaks it")
+    bad[end: end + 4] = b"\xff" * 4            # and the next chunk's flags and length varints
+    bad = bytes(bad)
+    with pytest.raises(oracle.McdfError) as eo:
+        oracle.mcdf_import(bad)
+    assert eo.value.code == snappy.native.E_LZ4_CORRUPT
+    good = _make_archive(oracle, 9, 78, chunk=1 << 16)[0]
+    for turn in ("short way", "overlapped", "plain order"):
+        monkeypatch.delenv("SNAPPY_OVERLAP_MIN_BYTES", raising=False)
+        monkeypatch.delenv("SNAPPY_MCDF_PLAIN_ORDER", raising=False)
+        if turn != "short way":
+            monkeypatch.setenv("SNAPPY_OVERLAP_MIN_BYTES", "0")
+        if turn == "plain order":
+            monkeypatch.setenv("SNAPPY_MCDF_PLAIN_ORDER", "1")
+        res = snappy.mcdf_decode_and_hash_batch([good, bad, good])
+        assert [r["status"] for r in res] == [0, snappy.native.E_LZ4_CORRUPT, 0], turn
+        with pytest.raises(snappy.native.SnappyError) as es:
+            snappy.mcdf_decode_and_hash(bad)
+        assert es.value.code == snappy.native.E_LZ4_CORRUPT, turn
