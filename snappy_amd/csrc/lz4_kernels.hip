@@ -38,6 +38,7 @@ constexpr int kWave = 64;
 constexpr uint32_t kCopyLength = 8;
 
 typedef __attribute__((address_space(3))) uint8_t LdsByte;  // an LDS address is 32 bits
+typedef __attribute__((address_space(3))) uint32_t LdsWord;
 
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 
@@ -67,7 +68,7 @@ __device__ __forceinline__ void wait_for_lds() { __builtin_amdgcn_s_waitcnt(0xC0
 // kStageBlocks blocks of 256 bytes per trip.  Tokens are parsed out of a
 // 256-byte window in registers, one dword per lane, which starts at any dword
 // and is moved on with one LDS read.
-constexpr uint32_t kStageBlocks = 24;  // 6 KiB per wave
+constexpr uint32_t kStageBlocks = 24;  // 6 KiB per wave (and behind them one dword per lane: see produce_batch)
 constexpr uint32_t kJumpBlocks = 4;    // staged after a jump (a long literal run was skipped)
 
 struct InputWindow {
@@ -714,23 +715,55 @@ __device__ __forceinline__ uint32_t produce_batch(InputWindow &win, uint32_t &ip
     const uint32_t q_limit = ip_limit + bias;
     uint32_t q = ip0 + bias;
     asm volatile("" : "+v"(q));
+    // Every instruction of a wave takes an issue slot whether the chain needs its result or not,
+    // so the step is written out with as few as it takes: five vector instructions.  With t the
+    // token and nb the byte behind it, the next token lies 3 + lit + [ml nibble = 15] +
+    // [lit = 15] (nb + 1) bytes on: (t + 1) >> 4 is lit + [ml nibble = 15], and
+    // e = t >= 0xF0 ? nb : -1 carries the extension byte or takes one off, which leaves 4 per
+    // token to add; those go into the reads' offset fields (w is the address less 4 per token
+    // of this turn).  The compare comes first and two instructions that do not need it follow,
+    // which is the distance a v_cndmask wants from the instruction that wrote its mask.  Where
+    // token n starts is not kept by a compare and a select per token either: it is written to
+    // LDS (one store, the same word from every lane) and lane n reads it after the walk.
+    // The step's LDS instructions are inside the statement as well, with its one wait (for the two
+    // reads; the store behind them may still be on its way): left to the compiler, the reads'
+    // destination registers are "maybe still being loaded" where the loop's paths join, and the
+    // wait it puts there lands behind the turn's first read and makes two round trips of one.
+    uint32_t *starts = win.stage + kStageBlocks * 64u;
+    const uint32_t starts_at = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((LdsByte *)starts));
+    wait_for_lds();
     while (n < quota && uni(q) <= q_limit) {
-#pragma unroll
-        for (uint32_t u = 0; u < 4u; ++u) {
-            // The token and the byte behind it: two byte reads (aligned whatever q is),
-            // issued together.
-            const LdsByte *a = (const LdsByte *)static_cast<uintptr_t>(q);
-            const uint32_t t = a[0], nb = a[1];
-            const uint32_t lit = t >> 4;
-            const uint32_t ext = lit == 15u ? nb + 1u : 0u;
-            my_ip = (lane == n) ? q : my_ip;
-            ++n;
-            q = q + lit + ext + ((t & 15u) == 15u ? 4u : 3u);
-            asm volatile("" : "+v"(q));
+        uint32_t w = q;
+        const uint32_t slot_at = starts_at + 4u * n;
+#define SNAPPY_LZ4_WALK_STEP(at, at1)                                                              \
+        {                                                                                            \
+            uint32_t t, nb, step, e;                                                                 \
+            asm volatile("ds_read_u8 %[t], %[w] offset:" #at "\n\t"                                 \
+                         "ds_read_u8 %[nb], %[w] offset:" #at1 "\n\t"                               \
+                         "ds_write_b32 %[slot], %[w] offset:" #at "\n\t"                            \
+                         "s_waitcnt lgkmcnt(1)\n\t"                                                 \
+                         "v_cmp_lt_u32_e32 vcc, %[top], %[t]\n\t"                                   \
+                         "v_add_u32_e32 %[step], 1, %[t]\n\t"                                       \
+                         "v_lshrrev_b32_e32 %[step], 4, %[step]\n\t"                                \
+                         "v_cndmask_b32_e32 %[e], -1, %[nb], vcc\n\t"                               \
+                         "v_add3_u32 %[w], %[step], %[w], %[e]"                                      \
+                         : [w] "+v"(w), [t] "=&v"(t), [nb] "=&v"(nb), [step] "=&v"(step), [e] "=&v"(e) \
+                         : [slot] "v"(slot_at), [top] "s"(0xEFu)                                     \
+                         : "vcc", "memory");                                                         \
         }
+        // Token k of the turn is read at w + 4 k and noted in slot k as w (less 4 k: added by the lane that reads it).
+        SNAPPY_LZ4_WALK_STEP(0, 1)
+        SNAPPY_LZ4_WALK_STEP(4, 5)
+        SNAPPY_LZ4_WALK_STEP(8, 9)
+        SNAPPY_LZ4_WALK_STEP(12, 13)
+#undef SNAPPY_LZ4_WALK_STEP
+        n += 4u;
+        q = w + 16u;
     }
     const uint32_t p = q - bias;
-    my_ip -= bias;  // lanes that recorded nothing stay above ip_limit (bias is far below 2^31)
+    // Lanes that have no token stay above ip_limit (bias is far below 2^31).
+    if (lane < n)
+        my_ip = starts[lane] + 4u * (lane & 3u) - bias;
     PHASE_MARK(clk, 0);
     if (n == 0) {
         walk = 4;
@@ -1272,7 +1305,7 @@ lz4_decode_kernel(const uint8_t *__restrict__ in_base, uint64_t in_alloc, uint8_
 {
     __shared__ __attribute__((aligned(16))) uint8_t ring[kHist];
     const uint32_t lane = threadIdx.x & (kWave - 1);
-    __shared__ __attribute__((aligned(16))) uint32_t stage[kStageBlocks * 64u];
+    __shared__ __attribute__((aligned(16))) uint32_t stage[kStageBlocks * 64u + kWave];
     // In an MCDF import the decoder runs next to a SHA-1 kernel whose waves issue an
     // instruction in nearly every slot of their SIMD.  A decoder wave spends most of its
     // time waiting for memory and LDS; when it is ready it should not queue behind that.
@@ -1307,7 +1340,7 @@ lz4_decode_pair_kernel(const uint8_t *__restrict__ in_base, uint64_t in_alloc, u
                        uint32_t *__restrict__ queue, uint32_t *__restrict__ status, uint32_t tuning)
 {
     __shared__ __attribute__((aligned(16))) uint8_t ring[kHist];
-    __shared__ __attribute__((aligned(16))) uint32_t stage[kStageBlocks * 64u];
+    __shared__ __attribute__((aligned(16))) uint32_t stage[kStageBlocks * 64u + kWave];
     __shared__ TeamShared shared;
     const uint32_t lane = threadIdx.x & (kWave - 1);
     // The parser's chain of dependent steps is what a chunk's time hangs on: when its
