@@ -836,7 +836,13 @@ __device__ __forceinline__ void batch_literals(const InputWindow &win, uint8_t *
     const uint32_t my_lit = lane < info.take ? desc.lit : 0u;
     const uint32_t my_op = desc.out_end - (desc.lit + desc.ml);
     // Source positions count bytes from win.aligned, as the stage's dwords do.
-    const LaneCopy c(my_op, my_lit, static_cast<int32_t>(desc.lip));
+    LaneCopy c(my_op, my_lit, static_cast<int32_t>(desc.lip));
+    // The last dword is stored whole even when the literals end inside it: the one to three
+    // bytes too many lie where the sequence's own match (four bytes at least) is written
+    // afterwards, by whoever does the matches, and nobody reads them before that.  So no tail.
+    // (The first dword stays exact: the bytes in front of a batch's first literals may be the
+    // end of a match the helper is still copying.)
+    c.full_end = c.count;
     // Lanes with nothing to copy read the stage's first dwords.
     const uint32_t *src = win.stage + (c.count ? c.sbase - static_cast<int32_t>(win.stage_block * 64u) : 0);
     for (uint32_t k0 = 0; __builtin_amdgcn_ballot_w64(k0 < c.count) != 0; k0 += kLitStep) {
@@ -846,8 +852,6 @@ __device__ __forceinline__ void batch_literals(const InputWindow &win, uint8_t *
             S[i] = src[k0 + i];
         lane_copy_step<kLitStep>(ring, c, k0, S);
     }
-    const uint32_t last = c.count ? c.count - 1u : 0u;
-    lane_copy_tail(ring, c, src[last], src[last + 1u]);
 }
 
 // Then the matches, and the batch's output from the ring to memory.  In a pair the
