@@ -666,6 +666,20 @@ struct BatchInfo {
     uint32_t start;       // output position of the first
     uint32_t end;         // and behind the last
     uint32_t valid_from;  // the ring holds output positions [valid_from, start)
+    uint32_t reach;       // sources down to start - reach are read from the ring, older ones from memory
+};
+
+// How the ring is shared out between a batch's output and the older output its matches may
+// still read from it (the reach).  With two waves the parser already writes the next batch's
+// literals while the helper copies this batch's matches, so reach + this batch + the next must
+// fit the ring; where a stream's matches read the ring behind a batch (offsets of a few hundred
+// bytes) the reach is worth 2 KiB, where they do not (offsets anywhere in 64 KiB) it is worth
+// nothing and the batches can be larger.  Decided batch by batch from where the last batch's
+// sources lay.
+struct RingShare {
+    uint32_t reach;       // of the next batch
+    uint32_t prev_reach;  // of the batch the helper may still be copying (0: none)
+    uint32_t prev_span;   // and its output bytes
 };
 
 // First half.  Returns the number of sequences taken (0: none, nothing changed but
@@ -676,7 +690,7 @@ template <typename Team>
 __device__ __forceinline__ uint32_t produce_batch(InputWindow &win, uint32_t &ip_io, uint32_t &op_io,
                                                   uint32_t valid_from, uint32_t iend, uint32_t oend,
                                                   uint32_t &walk, uint32_t lane, PhaseClock &clk,
-                                                  BatchLane &desc, BatchInfo &info)
+                                                  BatchLane &desc, BatchInfo &info, RingShare &share)
 {
     PHASE_MARK(clk, 5);
     const uint32_t ip0 = ip_io;  // uniform
@@ -796,10 +810,18 @@ __device__ __forceinline__ uint32_t produce_batch(InputWindow &win, uint32_t &ip
     const uint32_t my_op = out_end - out_len;
     const uint32_t mo = my_op + lit;
     const uint32_t s = mo - off;
-    const bool in_ring = s >= valid_from && s + Team::kReach >= start;
+    // This batch's share of the ring (see RingShare).
+    const uint32_t reach = Team::kAdaptive ? share.reach : Team::kReach;
+    uint32_t span = Team::kSpan;
+    if (Team::kAdaptive) {
+        span = (kHist - reach) / 2u;   // what two batches of this kind leave each other
+        const uint32_t room = kHist - share.prev_reach - share.prev_span;   // beside the batch in the helper's hands
+        span = span < room ? span : room;
+    }
+    const bool in_ring = s >= valid_from && s + reach >= start;
     const bool bad = !walked || lit > kBatchLit || ml > kBatchMatch || (off < ml && off < 4u * kMatchStep) ||
                      off > mo || off == 0u || after + 4u > iend || out_end + 16u > oend ||
-                     out_end - start > Team::kSpan || (!in_ring && s + ml > start) ||
+                     out_end - start > span || (!in_ring && s + ml > start) ||
                      (off < ml && !in_ring);
     const uint64_t stop = __builtin_amdgcn_ballot_w64(bad);
     const uint32_t take = stop ? static_cast<uint32_t>(__builtin_ctzll(stop)) : kWave;
@@ -817,6 +839,23 @@ __device__ __forceinline__ uint32_t produce_batch(InputWindow &win, uint32_t &ip
     info.start = start;
     info.end = op_io;
     info.valid_from = valid_from;
+    info.reach = reach;
+    if (Team::kAdaptive) {
+        // Where this batch's older sources lay decides the next batch's reach: 2 KiB when a good
+        // part of them lies between 512 bytes and 2 KiB behind the batch, else 512 bytes (batches
+        // of up to 3840 bytes instead of 3072).  That is the choice when nearly all lie within
+        // 512 bytes, and also when most lie further back than any reach (offsets anywhere in
+        // 64 KiB): the 512 bytes then still keep the ring for a source that begins in front of the
+        // batch and ends inside it (no reach at all measured 3 % slower on such streams: such a
+        // source ends its batch).
+        const bool older = lane < take && s < start;
+        const uint32_t n_older = __builtin_popcountll(__builtin_amdgcn_ballot_w64(older));
+        const uint32_t n_2k = __builtin_popcountll(__builtin_amdgcn_ballot_w64(older && s + 2048u >= start));
+        const uint32_t n_512 = __builtin_popcountll(__builtin_amdgcn_ballot_w64(older && s + 512u >= start));
+        share.reach = (4u * n_2k < n_older || 8u * n_512 >= 7u * n_2k) ? 512u : 2048u;
+        share.prev_reach = reach;
+        share.prev_span = op_io - start;
+    }
     PHASE_MARK(clk, 1);
 #ifdef SNAPPY_LZ4_PHASE_SWITCHES
     clk.acc[7] += (uint64_t(1) << 32) | take;  // batches taken, sequences in them
@@ -870,7 +909,7 @@ __device__ __forceinline__ void batch_matches(uint8_t *dst, uint8_t *ring, const
     const uint32_t my_op = out_end - (lit + ml);
     const uint32_t mo = my_op + lit;
     const uint32_t s = mo - off;
-    const bool in_ring = s >= info.valid_from && s + Team::kReach >= start;
+    const bool in_ring = s >= info.valid_from && s + info.reach >= start;
 
     // Everything a batch produces is written to the ring only and goes to memory in
     // one piece at the end (flush_ring).  Matches whose source is older than the
@@ -1027,6 +1066,7 @@ struct TeamShared {
 
 struct SoloTeam {
     static constexpr uint32_t kSpan = kSoloSpan, kReach = kSoloReach;
+    static constexpr bool kAdaptive = false;
     __device__ __forceinline__ void sync() {}
     __device__ __forceinline__ void copy(uint8_t *dst, const uint8_t *src, uint32_t n, uint32_t lane)
     {
@@ -1043,7 +1083,8 @@ struct SoloTeam {
 
 struct PairTeam {
     static constexpr uint32_t kCopyDepth = 4;
-    static constexpr uint32_t kSpan = kPairSpan, kReach = kPairReach;
+    static constexpr uint32_t kSpan = kPairSpan, kReach = kPairReach;   // the shares a chunk starts with
+    static constexpr bool kAdaptive = true;
     TeamShared *sh;
     uint32_t seq;   // commands published so far
     bool pending;   // the helper may still be busy with a batch
@@ -1126,6 +1167,7 @@ __device__ void helper_loop(TeamShared *sh, uint8_t *ring, uint32_t lane, uint32
             info.start = uni(sh->info[slot].start);
             info.end = uni(sh->info[slot].end);
             info.valid_from = uni(sh->info[slot].valid_from);
+            info.reach = uni(sh->info[slot].reach);
             batch_matches<PairTeam>(known_global(sh->dst[slot]), ring, desc, info, lane, tuning, clk);
             wait_for_memory();  // the flush is in memory before the parser is told so
         } else if (cmd == kCmdCopy) {
@@ -1163,6 +1205,7 @@ __device__ bool decode_sequences(const uint8_t *__restrict__ in_base, uint64_t i
     uint32_t valid_from = 0; // uniform: the ring holds output positions [valid_from, op)
     uint32_t walk = kWave;   // uniform: tokens the next batch looks at
     uint32_t misses = 0, skip = 0;  // uniform: back-off of the batch attempts on streams of long sequences
+    RingShare share = {Team::kReach, 0u, 0u};
     const uint8_t *src_al = src - in_shift;
 
     // A chunk may be asked for in part (its first bytes hold an archive's header): the
@@ -1176,7 +1219,8 @@ __device__ bool decode_sequences(const uint8_t *__restrict__ in_base, uint64_t i
         } else if (!(tuning & 1u)) {
             BatchLane desc;
             BatchInfo info;
-            const uint32_t taken = produce_batch<Team>(win, ip, op, valid_from, iend, oend, walk, lane, clk, desc, info);
+            const uint32_t taken = produce_batch<Team>(win, ip, op, valid_from, iend, oend, walk, lane, clk, desc, info,
+                                                       share);
             if (taken != 0u)
                 team.batch(win, src_al, dst, ring, desc, info, lane, tuning, clk);
             if (taken >= 16u)
@@ -1187,6 +1231,7 @@ __device__ bool decode_sequences(const uint8_t *__restrict__ in_base, uint64_t i
         }
         // What follows writes the ring and memory itself: the batches before it are finished first.
         team.sync();
+        share.prev_reach = share.prev_span = 0;
         if (ip >= iend)
             return false;
         uint32_t bytes = uni(win.peek32(ip, lane));
