@@ -667,6 +667,8 @@ struct BatchInfo {
     uint32_t end;         // and behind the last
     uint32_t valid_from;  // the ring holds output positions [valid_from, start)
     uint32_t reach;       // sources down to start - reach are read from the ring, older ones from memory
+    uint32_t stage_block; // number of the first staged block (the stage as the batch's literals are read from it)
+    uint32_t literals;    // != 0: the literals are still to be copied (by whoever takes the batch)
 };
 
 // How the ring is shared out between a batch's output and the older output its matches may
@@ -690,7 +692,7 @@ template <typename Team>
 __device__ __forceinline__ uint32_t produce_batch(InputWindow &win, uint32_t &ip_io, uint32_t &op_io,
                                                   uint32_t valid_from, uint32_t iend, uint32_t oend,
                                                   uint32_t &walk, uint32_t lane, PhaseClock &clk,
-                                                  BatchLane &desc, BatchInfo &info, RingShare &share)
+                                                  BatchLane &desc, BatchInfo &info, RingShare &share, Team &team)
 {
     PHASE_MARK(clk, 5);
     const uint32_t ip0 = ip_io;  // uniform
@@ -702,6 +704,7 @@ __device__ __forceinline__ uint32_t produce_batch(InputWindow &win, uint32_t &ip
         // taken lately; otherwise the one-at-a-time code stages what it needs.
         if (!likely || ip0 + kBatchInput > iend)
             return 0;
+        team.before_restage();
         win.restage(ip0 >> 8, true, lane);
     }
     const uint32_t stage_end = win.stage_end();
@@ -840,6 +843,8 @@ __device__ __forceinline__ uint32_t produce_batch(InputWindow &win, uint32_t &ip
     info.end = op_io;
     info.valid_from = valid_from;
     info.reach = reach;
+    info.stage_block = win.stage_block;
+    info.literals = 1u;
     if (Team::kAdaptive) {
         // Where this batch's older sources lay decides the next batch's reach: 2 KiB when a good
         // part of them lies between 512 bytes and 2 KiB behind the batch, else 512 bytes (batches
@@ -1062,12 +1067,17 @@ struct TeamShared {
     const uint8_t *src[2];
     BatchInfo info[2];
     uint32_t lanes[2][5][kWave];
+    // Written by the helper: commands it has finished (written just before it waits for the
+    // next one), and batches whose literals it has finished reading out of the stage.
+    uint32_t helper_done;
+    uint32_t stage_read;
 };
 
 struct SoloTeam {
     static constexpr uint32_t kSpan = kSoloSpan, kReach = kSoloReach;
     static constexpr bool kAdaptive = false;
     __device__ __forceinline__ void sync() {}
+    __device__ __forceinline__ void before_restage() {}
     __device__ __forceinline__ void copy(uint8_t *dst, const uint8_t *src, uint32_t n, uint32_t lane)
     {
         copy_run(dst, src, n, lane);
@@ -1088,6 +1098,18 @@ struct PairTeam {
     TeamShared *sh;
     uint32_t seq;   // commands published so far
     bool pending;   // the helper may still be busy with a batch
+    uint32_t stage_lent = 0;   // != 0: the helper reads the stage until sh->stage_read reaches this
+
+    // The helper copies a batch's literals out of the stage when it is idle at the hand-over:
+    // the stage must then stay as it is until it has.
+    __device__ __forceinline__ void before_restage()
+    {
+        if (stage_lent == 0u)
+            return;
+        while (uni(__hip_atomic_load(&sh->stage_read, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < stage_lent)
+            __builtin_amdgcn_s_sleep(1);
+        stage_lent = 0u;
+    }
 
     // Every lane stores the same words.  The parser's own stores to memory are
     // complete before the helper may read what they wrote.
@@ -1107,6 +1129,7 @@ struct PairTeam {
     {
         if (pending)
             publish(kCmdSync, nullptr, nullptr, 0);
+        stage_lent = 0u;   // the helper has finished everything
     }
     __device__ __forceinline__ void copy(uint8_t *dst, const uint8_t *src, uint32_t n, uint32_t lane)
     {
@@ -1125,10 +1148,21 @@ struct PairTeam {
                                           const BatchLane &desc, const BatchInfo &info, uint32_t lane,
                                           uint32_t tuning, PhaseClock &clk)
     {
-        // The literals go into the ring behind the output of the batch the helper may
-        // still be copying (kPairSpan and kPairReach keep the two apart); the barrier in
-        // publish() comes after these LDS writes have completed.
-        batch_literals(win, ring, desc, info, lane, tuning);
+        // Who copies the literals is decided at the hand-over: the helper when it sits idle, waiting
+        // for this command (the walk is the chunk's critical path, and on streams of short sequences
+        // the helper has time to spare); the parser when the helper is still busy with the batch
+        // before, so that the copy runs beside that work.  The parser's copy goes into the ring
+        // behind the output of the batch the helper may still be copying (RingShare keeps the two
+        // apart); the barrier in publish() comes after these LDS writes have completed.
+        const bool helper_idle =
+            uni(__hip_atomic_load(&sh->helper_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) == seq;
+        BatchInfo handed = info;
+        if (helper_idle && !(tuning & 64u)) {
+            stage_lent = seq + 1u;
+        } else {
+            batch_literals(win, ring, desc, info, lane, tuning);
+            handed.literals = 0u;
+        }
         PHASE_MARK(clk, 2);
         const uint32_t slot = seq & 1u;
         sh->lanes[slot][0][lane] = desc.lip;
@@ -1136,17 +1170,18 @@ struct PairTeam {
         sh->lanes[slot][2][lane] = desc.ml;
         sh->lanes[slot][3][lane] = desc.off;
         sh->lanes[slot][4][lane] = desc.out_end;
-        sh->info[slot] = info;
+        sh->info[slot] = handed;
         publish(kCmdBatch, dst, src_al, 0);
     }
 };
 
 // The helper wave of a pair: carries out the parser's commands until told to leave.
-__device__ void helper_loop(TeamShared *sh, uint8_t *ring, uint32_t lane, uint32_t tuning)
+__device__ void helper_loop(TeamShared *sh, uint8_t *ring, uint32_t *stage, uint32_t lane, uint32_t tuning)
 {
     PhaseClock clk;
     clk.start();
     for (uint32_t seq = 0;; ++seq) {
+        __hip_atomic_store(&sh->helper_done, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         __syncthreads();
         const uint32_t slot = seq & 1u;
         const uint32_t cmd = uni(sh->cmd[slot]);
@@ -1168,6 +1203,16 @@ __device__ void helper_loop(TeamShared *sh, uint8_t *ring, uint32_t lane, uint32
             info.end = uni(sh->info[slot].end);
             info.valid_from = uni(sh->info[slot].valid_from);
             info.reach = uni(sh->info[slot].reach);
+            if (uni(sh->info[slot].literals) != 0u) {
+                InputWindow from;
+                from.stage = stage;
+                from.stage_block = uni(sh->info[slot].stage_block);
+                batch_literals(from, ring, desc, info, lane, tuning);
+                // The literals' reads have been carried out when this store is (one wave's LDS
+                // operations take effect in order): the parser may refill the stage.
+                __hip_atomic_store(&sh->stage_read, seq + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                PHASE_MARK(clk, 2);
+            }
             batch_matches<PairTeam>(known_global(sh->dst[slot]), ring, desc, info, lane, tuning, clk);
             wait_for_memory();  // the flush is in memory before the parser is told so
         } else if (cmd == kCmdCopy) {
@@ -1220,7 +1265,7 @@ __device__ bool decode_sequences(const uint8_t *__restrict__ in_base, uint64_t i
             BatchLane desc;
             BatchInfo info;
             const uint32_t taken = produce_batch<Team>(win, ip, op, valid_from, iend, oend, walk, lane, clk, desc, info,
-                                                       share);
+                                                       share, team);
             if (taken != 0u)
                 team.batch(win, src_al, dst, ring, desc, info, lane, tuning, clk);
             if (taken >= 16u)
@@ -1397,10 +1442,11 @@ lz4_decode_pair_kernel(const uint8_t *__restrict__ in_base, uint64_t in_alloc, u
     // kernel's waves in an import).
     if (threadIdx.x >= kWave) {
         __builtin_amdgcn_s_setprio(2);
-        helper_loop(&shared, ring, lane, tuning);
+        helper_loop(&shared, ring, stage, lane, tuning);
         return;
     }
     __builtin_amdgcn_s_setprio(3);
+    shared.stage_read = 0;   // before the first command (the helper only ever raises it)
     PairTeam team{&shared, 0u, false};
     for (;;) {
         const uint32_t i = wave_claim(queue, 1u, lane);
@@ -1450,7 +1496,8 @@ hipError_t launch_lz4_decode(const uint8_t *d_in, uint64_t in_alloc, uint8_t *d_
         pad_lds = (64u << 10) - kLdsUsed;
     }
     // SNAPPY_LZ4_TUNING, bit 0: every sequence takes the one-at-a-time path (for comparisons);
-    // bit 5 (32): one wave per chunk instead of two.
+    // bit 5 (32): one wave per chunk instead of two; bit 6 (64): the parsing wave copies every
+    // batch's literals itself (the helper takes none).
     static const uint32_t tuning = [] {
         const char *env = std::getenv("SNAPPY_LZ4_TUNING");
         return env ? static_cast<uint32_t>(std::strtoul(env, nullptr, 0)) : 0u;

@@ -295,11 +295,12 @@ def test_dense_short_sequences_corrupted(snappy, oracle):
             assert got == want, pos
 
 
-@pytest.mark.parametrize("tuning", ["1", "32", "33"])
+@pytest.mark.parametrize("tuning", ["1", "32", "33", "64"])
 def test_other_ways_through_the_decoder(tuning):
     """The same block and stream tests with the batch path switched off (bit 0), with one wave per
-    chunk instead of two (bit 5), and with both (the switches are read once per process, hence the
-    child): every way through the decoder stays covered."""
+    chunk instead of two (bit 5), with both, and with every batch's literals copied by the parsing
+    wave (bit 6; otherwise the helper takes them when it is idle) (the switches are read once per
+    process, hence the child): every way through the decoder stays covered."""
     import os
     import subprocess
     import sys
