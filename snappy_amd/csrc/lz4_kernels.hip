@@ -901,10 +901,13 @@ __device__ __forceinline__ void batch_literals(const InputWindow &win, uint8_t *
 // Then the matches, and the batch's output from the ring to memory.  In a pair the
 // helper wave does this while the parser walks on, and the parser may already be
 // writing the next batch's literals into the ring behind info.end.
+// lit_from (may be null): the stage, when the batch's literals are still to be copied
+// (info.literals); *lit_done is then set to lit_done_value once they have been read.
 template <typename Team>
 __device__ __forceinline__ void batch_matches(uint8_t *dst, uint8_t *ring, const BatchLane &desc,
                                               const BatchInfo &info, uint32_t lane, uint32_t tuning,
-                                              PhaseClock &clk)
+                                              PhaseClock &clk, const InputWindow *lit_from = nullptr,
+                                              uint32_t *lit_done = nullptr, uint32_t lit_done_value = 0)
 {
     const uint32_t take = info.take, start = info.start;
     const bool mine = lane < take;
@@ -957,6 +960,16 @@ __device__ __forceinline__ void batch_matches(uint8_t *dst, uint8_t *ring, const
     for (uint32_t d = 0; d < kFarDepth; ++d)
         if (d < far_steps)
             far_loads(d * kFarStep, ff[d]);
+
+    // The literals, when they came over with the batch: behind the far loads, whose round trip
+    // they then run beside (they touch LDS alone), and in front of everything that reads the ring.
+    if (lit_from != nullptr && info.literals != 0u) {
+        batch_literals(*lit_from, ring, desc, info, lane, tuning);
+        // The literals' reads have been carried out when this store is (one wave's LDS operations
+        // take effect in order): the parser may refill the stage.
+        __hip_atomic_store(lit_done, lit_done_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        PHASE_MARK(clk, 2);
+    }
 
     // Matches that read the ring are copied in rounds: a match is copied once every
     // match whose output it reads has been.  These are the sequences from the one that
@@ -1203,17 +1216,12 @@ __device__ void helper_loop(TeamShared *sh, uint8_t *ring, uint32_t *stage, uint
             info.end = uni(sh->info[slot].end);
             info.valid_from = uni(sh->info[slot].valid_from);
             info.reach = uni(sh->info[slot].reach);
-            if (uni(sh->info[slot].literals) != 0u) {
-                InputWindow from;
-                from.stage = stage;
-                from.stage_block = uni(sh->info[slot].stage_block);
-                batch_literals(from, ring, desc, info, lane, tuning);
-                // The literals' reads have been carried out when this store is (one wave's LDS
-                // operations take effect in order): the parser may refill the stage.
-                __hip_atomic_store(&sh->stage_read, seq + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                PHASE_MARK(clk, 2);
-            }
-            batch_matches<PairTeam>(known_global(sh->dst[slot]), ring, desc, info, lane, tuning, clk);
+            info.literals = uni(sh->info[slot].literals);
+            InputWindow from;
+            from.stage = stage;
+            from.stage_block = uni(sh->info[slot].stage_block);
+            batch_matches<PairTeam>(known_global(sh->dst[slot]), ring, desc, info, lane, tuning, clk, &from,
+                                    &sh->stage_read, seq + 1u);
             wait_for_memory();  // the flush is in memory before the parser is told so
         } else if (cmd == kCmdCopy) {
             const uint32_t n = uni(sh->len[slot]);
