@@ -256,6 +256,41 @@ def test_dense_short_sequences(snappy, oracle, max_lit, max_match, max_off, over
     assert got == want
 
 
+def test_dense_sequences_that_change_character_inside_a_chunk(snappy, oracle):
+    """One chunk whose sequences go from near sources to sources anywhere, to repeated short
+    patterns, to literal runs and matches of hundreds of bytes and back, every few hundred
+    sequences: the decoder re-decides batch by batch how the ring is shared between the reach
+    and the batch, which wave copies a batch's literals, and whether to take batches at all."""
+    rng = np.random.default_rng(20261)
+    regimes = [(8, 20, 2048, 0.0), (24, 36, 65535, 0.0), (3, 8, 64, 0.5), (120, 250, 65535, 0.05),
+               (60, 30, 600, 0.0), (0, 12, 65535, 0.0), (300, 300, 65535, 0.1), (24, 36, 400, 0.2)]
+    stream, want = b"", b""
+    for rounds in (1, 3):
+        parts, produced = [], 0
+        for _ in range(rounds):
+            for k in rng.permutation(len(regimes)):
+                max_lit, max_match, max_off, overlap = regimes[k]
+                for lit_bytes, off, ml in _random_sequences(rng, int(rng.integers(40, 400)), max_lit, max_match, max_off,
+                                                            overlap)[:-1]:
+                    # offsets were drawn against this piece's own output: against the whole chunk's they stay valid
+                    # once something precedes the piece
+                    off = min(off, produced + len(lit_bytes)) if produced + len(lit_bytes) else off
+                    if off == 0:
+                        continue
+                    parts.append((lit_bytes, off, ml))
+                    produced += len(lit_bytes) + ml
+        parts.append((b"the end of it", None, None))
+        blk, out = H.block(parts)
+        assert len(blk) <= len(out) and len(out) < (1 << 20) * 4
+        stream += H.chunk(blk, len(out), True)
+        want += out
+    st_o, got_o = oracle.lz4net_decode(stream)
+    assert st_o == 0 and got_o == want
+    st, got = _gpu_decode(snappy, stream)
+    assert st == 0
+    assert got == want
+
+
 def test_dense_short_sequences_at_every_limit(snappy, oracle):
     """One sequence of each combination of boundary lengths and offsets, surrounded by plain ones."""
     rng = np.random.default_rng(11)
