@@ -6,6 +6,7 @@
 // one decode launch and one hash launch: an archive is only 64-512 chunks, too
 // few to occupy the GPU on its own.
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -226,23 +227,62 @@ int import_batch_overlapped(SlotLease &lease, std::vector<StreamJob> &jobs, std:
     std::vector<uint64_t> offsets, lengths;
     std::vector<std::pair<size_t, size_t>> owner;  // (archive, file)
     bool header_beyond = false;
-    for (size_t a = 0; a < n; ++a) {
+    // Header by header (JSON text of some tens of KB each), on a few threads when the headers are
+    // all on the host already: 64 archives' headers took 3.4 ms on one.
+    struct Parsed {
+        std::vector<uint64_t> offsets, lengths;
+        std::vector<std::pair<size_t, size_t>> owner;
+        bool beyond = false;
+        int st = SNAPPY_OK;
+    };
+    std::vector<Parsed> parsed(n);
+    auto parse_one = [&](size_t a) {
         ArchiveState &as = states[a];
         // A stream error ends the import before anything looks at the header; a first
         // chunk that does not decode is the stream's first error.
         if (first_of[a] != SIZE_MAX && first_status[first_of[a]] != 0)
             jobs[a].status = as.status = SNAPPY_E_LZ4_CORRUPT;
         if (as.status != SNAPPY_OK)
-            continue;
+            return;
         const Lz4Chunk *fc = first_of[a] == SIZE_MAX ? nullptr : &firsts[first_of[a]];
         const uint64_t avail = !fc ? 0 : (fc->prefix_len ? fc->prefix_len : fc->orig_len);
         const bool on_host = prefixes && fc;
-        st = header_and_slices(arena, jobs[a], a, avail, as, digests_out[a], offsets, lengths, owner, &header_beyond,
-                               on_host ? prefixes + first_of[a] * size_t(kHeaderPrefix) : nullptr,
-                               on_host ? std::min<uint64_t>(fc->orig_len, kHeaderPrefix) : 0);
-        if (st != SNAPPY_OK)
-            return st;
+        Parsed &out = parsed[a];
+        try {
+            out.st = header_and_slices(arena, jobs[a], a, avail, as, digests_out[a], out.offsets, out.lengths, out.owner,
+                                       &out.beyond, on_host ? prefixes + first_of[a] * size_t(kHeaderPrefix) : nullptr,
+                                       on_host ? std::min<uint64_t>(fc->orig_len, kHeaderPrefix) : 0);
+        } catch (const std::bad_alloc &) {
+            out.st = SNAPPY_E_NOMEM;
+        } catch (...) {
+            out.st = SNAPPY_E_INVALID_ARG;
+        }
+    };
+    {
+        std::atomic<size_t> next{0};
+        auto worker = [&] {
+            for (size_t a; (a = next.fetch_add(1)) < n;)
+                parse_one(a);
+        };
+        std::vector<std::thread> helpers;
+        if (prefixes && n >= 8)   // (without the host copies a header is fetched by blocking copies: one thread)
+            for (unsigned t = 1; t < 8 && t < n / 2; ++t)
+                if (!try_spawn(helpers, worker))
+                    break;
+        worker();
+        for (auto &h : helpers)
+            h.join();
     }
+    for (size_t a = 0; a < n; ++a) {
+        Parsed &in = parsed[a];
+        if (in.st != SNAPPY_OK)
+            return in.st;
+        header_beyond = header_beyond || in.beyond;
+        offsets.insert(offsets.end(), in.offsets.begin(), in.offsets.end());
+        lengths.insert(lengths.end(), in.lengths.begin(), in.lengths.end());
+        owner.insert(owner.end(), in.owner.begin(), in.owner.end());
+    }
+    parsed.clear();
     if (trace)
         std::fprintf(stderr, "[import] streams laid out at %.1f ms, first chunks sent at %.1f, decoded at %.1f (kernel %.2f ms), "
                              "headers of %zu archives parsed at %.1f ms\n",
