@@ -720,7 +720,7 @@ __device__ __forceinline__ uint32_t produce_batch(InputWindow &win, uint32_t &ip
     // per token, with no hop through the scalar unit (a walk over a 256-byte register
     // window with v_readlane took 230 clocks per token plus 620 per window move).
     const uint32_t ip_limit = stage_end - kBatchInput;  // at least kJumpBlocks blocks are staged
-    const uint32_t quota = (walk + 3u) & ~3u;           // whole turns; at most 64
+    const uint32_t quota = (walk + 7u) & ~7u;           // whole turns; at most 64
     uint32_t n = 0;
     uint32_t my_ip = 0xFFFFFFFFu;  // lane j: sequence j
     // The chain stays in vector registers: the value is the same in every lane, which
@@ -773,14 +773,18 @@ __device__ __forceinline__ uint32_t produce_batch(InputWindow &win, uint32_t &ip
         SNAPPY_LZ4_WALK_STEP(4, 5)
         SNAPPY_LZ4_WALK_STEP(8, 9)
         SNAPPY_LZ4_WALK_STEP(12, 13)
+        SNAPPY_LZ4_WALK_STEP(16, 17)
+        SNAPPY_LZ4_WALK_STEP(20, 21)
+        SNAPPY_LZ4_WALK_STEP(24, 25)
+        SNAPPY_LZ4_WALK_STEP(28, 29)
 #undef SNAPPY_LZ4_WALK_STEP
-        n += 4u;
-        q = w + 16u;
+        n += 8u;
+        q = w + 32u;
     }
     const uint32_t p = q - bias;
     // Lanes that have no token stay above ip_limit (bias is far below 2^31).
     if (lane < n)
-        my_ip = starts[lane] + 4u * (lane & 3u) - bias;
+        my_ip = starts[lane] + 4u * (lane & 7u) - bias;
     PHASE_MARK(clk, 0);
     if (n == 0) {
         walk = 4;
