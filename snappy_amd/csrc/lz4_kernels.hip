@@ -290,10 +290,12 @@ __device__ __forceinline__ void copy_run(uint8_t *dst, const uint8_t *src, uint3
 // written as dst[i] = dst[i mod period - period], which reads only bytes that
 // existed before the match; the rest is filled by doubling.
 constexpr uint32_t kPeriodSpan = 4096;
+constexpr uint32_t kRingBytes = 8192;   // = kHist, declared below with the ring's other figures
 
+// ring (may be null): the LDS ring when it holds the pattern, whose first byte is output position ring_pos.
 template <typename Team>
 __device__ __forceinline__ void copy_periodic(Team &team, uint8_t *dst, uint32_t period, uint32_t n,
-                                              uint32_t lane)
+                                              uint32_t lane, const uint8_t *ring = nullptr, uint32_t ring_pos = 0)
 {
     const uint8_t *pat = dst - period;
     const uint32_t reps = (kPeriodSpan + period - 1u) / period;
@@ -303,6 +305,36 @@ __device__ __forceinline__ void copy_periodic(Team &team, uint8_t *dst, uint32_t
         // Long pattern: each repetition is a plain copy of the pattern itself.
         for (uint32_t at = 0; at < head; at += period)
             team.copy(dst + at, pat, (head - at < period) ? head - at : period, lane);
+    } else if (ring != nullptr) {
+        // The pattern is in the ring (it is what the sequence's literals and the matches before
+        // them just wrote): read from there, byte r of the pattern at ring position ring_pos + r.
+        // From memory every turn of this loop waited for a round trip to the L2, a microsecond,
+        // and a pattern of 40 bytes repeated 40 times is six turns.
+        uint32_t r = lane % period;
+        const uint32_t step = kWave % period;
+        uint32_t i = lane;
+        // Eight rows of 64 bytes per turn: their reads are in flight together.  (The rows left
+        // over go one by one: a last turn that stores only the rows it has, each store under its
+        // own test, measured slower than that.)
+#pragma clang loop vectorize(disable) unroll(disable)
+        for (; i + 7u * kWave < head; i += 8u * kWave) {
+            uint8_t v[8];
+#pragma unroll
+            for (uint32_t k = 0; k < 8u; ++k) {
+                v[k] = ring[(ring_pos + r) & (kRingBytes - 1u)];
+                r += step;
+                r -= (r >= period) ? period : 0u;
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < 8u; ++k)
+                dst[i + k * kWave] = v[k];
+        }
+#pragma clang loop vectorize(disable) unroll(disable)
+        for (; i < head; i += kWave) {
+            dst[i] = ring[(ring_pos + r) & (kRingBytes - 1u)];
+            r += step;
+            r -= (r >= period) ? period : 0u;
+        }
     } else {
         uint32_t r = lane % period;
         const uint32_t step = kWave % period;
@@ -349,6 +381,7 @@ __device__ __forceinline__ void copy_periodic(Team &team, uint8_t *dst, uint32_t
 // in LDS, from which short matches read.  The ring holds the output positions
 // [valid_from, op); long copies bypass it and reset valid_from.
 constexpr uint32_t kHist = 8192;       // bytes of recent output per wave in LDS
+static_assert(kHist == kRingBytes, "one ring");
 constexpr uint32_t kShortLit = 192;    // longest literal run served from the window registers
 constexpr uint32_t kShortMatch = 512;  // longest match served from the ring
 
@@ -1385,7 +1418,8 @@ __device__ bool decode_sequences(const uint8_t *__restrict__ in_base, uint64_t i
             if (offset >= ml) {
                 team.copy(mdst, msrc, ml, lane);
             } else {
-                copy_periodic(team, mdst, offset, ml, lane);
+                const bool in_ring = op - offset >= valid_from && offset <= kHist;
+                copy_periodic(team, mdst, offset, ml, lane, in_ring ? ring : nullptr, op - offset);
             }
             valid_from = op + ml;
         }
