@@ -297,6 +297,28 @@ template <typename Team>
 __device__ __forceinline__ void copy_periodic(Team &team, uint8_t *dst, uint32_t period, uint32_t n,
                                               uint32_t lane, const uint8_t *ring = nullptr, uint32_t ring_pos = 0)
 {
+    if (ring != nullptr && period <= 16u && (16u % period) == 0u && n >= 4u * kWave) {
+        // A run of one byte, or of a pattern of 2, 4, 8 or 16 bytes (zero padding, a repeated
+        // value): every group of 16 bytes of the run is the same, so it is put together once,
+        // out of the ring, and stored over and over.  Nothing is read back from memory, where
+        // the general way below doubles what it has written.
+        uint32_t w[4];
+#pragma unroll
+        for (uint32_t q = 0; q < 4u; ++q) {
+            uint32_t word = 0;
+#pragma unroll
+            for (uint32_t j = 0; j < 4u; ++j)
+                word |= static_cast<uint32_t>(ring[(ring_pos + ((4u * q + j) & (period - 1u))) & (kRingBytes - 1u)]) << (8u * j);
+            w[q] = word;
+        }
+        const uint4 v = make_uint4(w[0], w[1], w[2], w[3]);
+        const uint32_t groups = n >> 4;
+        for (uint32_t g = lane; g < groups; g += kWave)
+            __builtin_memcpy(dst + 16u * g, &v, 16);
+        if (lane < (n & 15u))
+            dst[16u * groups + lane] = ring[(ring_pos + (lane & (period - 1u))) & (kRingBytes - 1u)];
+        return;
+    }
     const uint8_t *pat = dst - period;
     const uint32_t reps = (kPeriodSpan + period - 1u) / period;
     const uint32_t span = reps * period;

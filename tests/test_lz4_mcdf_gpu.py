@@ -291,6 +291,35 @@ def test_dense_sequences_that_change_character_inside_a_chunk(snappy, oracle):
     assert got == want
 
 
+def test_dense_repeated_patterns_of_every_short_period(snappy, oracle):
+    """Matches that repeat a pattern (offset < length): every period from 1 to 40 and a few longer
+    ones, lengths from a few bytes to beyond 4 KiB, at every alignment of the output position
+    (the literals in front vary in length): the runs of 1, 2, 4, 8 and 16 bytes are stored as one
+    repeated 16-byte group, the other short periods are read out of the ring row by row, the long
+    ones copied pattern by pattern."""
+    rng = np.random.default_rng(5150)
+    periods = list(range(1, 41)) + [63, 64, 65, 127, 255, 256, 257, 600, 5000]
+    stream, want = b"", b""
+    for lengths in ((5, 17, 63, 64, 255, 256, 257), (300, 1000, 4095, 4096, 4097, 9000), (20000, 70000)):
+        parts = [(bytes(rng.integers(0, 256, size=5200, dtype=np.uint8)), 5200, 4)]   # something to be far from
+        for period in periods:
+            for ml in lengths:
+                if ml <= period:
+                    continue
+                lit = bytes(rng.integers(0, 256, size=period + int(rng.integers(0, 4)), dtype=np.uint8))
+                parts.append((lit, period, ml))
+        parts.append((b"the end of it", None, None))
+        blk, out = H.block(parts)
+        assert len(blk) < len(out)
+        stream += H.chunk(blk, len(out), True)
+        want += out
+    st_o, got_o = oracle.lz4net_decode(stream)
+    assert st_o == 0 and got_o == want
+    st, got = _gpu_decode(snappy, stream)
+    assert st == 0
+    assert got == want
+
+
 def test_dense_short_sequences_at_every_limit(snappy, oracle):
     """One sequence of each combination of boundary lengths and offsets, surrounded by plain ones."""
     rng = np.random.default_rng(11)
