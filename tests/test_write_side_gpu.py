@@ -62,6 +62,24 @@ def test_encode_roundtrip_through_oracle(snappy, oracle, kind, size, block):
         assert not any(c for c, _, _ in parts)          # stored: random bytes do not shrink
 
 
+def test_encode_lengths_around_the_steps(snappy, oracle):
+    """The compressor looks at 64 or 256 positions per trip, extends a match 64 and then 256 bytes
+    per step (a lane's dword may straddle the last byte a match may cover) and copies literals in
+    passes of 256 and 1024 bytes: every input length around those figures, on content that is one
+    long match (zeros, a 45-byte phrase), one long literal run (random) and a mix of both."""
+    sizes = list(range(60, 84)) + list(range(250, 345)) + list(range(1016, 1050)) + list(range(1270, 1300)) + \
+        [2303, 2304, 2305, 4607, 5121, 65535, 65536, 65537, 65800]
+    phrase = b"the quick brown fox jumps over the lazy dog. "
+    noise = H.random_bytes(70_000, 21)
+    for n in sizes:
+        half = n // 2
+        for data in (b"\0" * n, (phrase * (n // 45 + 1))[:n], noise[:n],
+                     noise[:half] + noise[:n - half],            # second half repeats the first
+                     noise[:n // 3] + b"\0" * (n - n // 3)):
+            stream = snappy.lz4net_encode(data)
+            assert oracle.lz4net_decode(stream) == (0, data), n
+
+
 def test_blocks_decode_with_liblz4(snappy):
     name = ctypes.util.find_library("lz4")
     if not name:
