@@ -232,9 +232,28 @@ def make_mcdf_archive(payload_bytes: int, n_files: int, rng: np.random.Generator
     native.check(L.snappy_lz4net_encode_bound(payload.size, 1 << 20, ctypes.byref(cap)), "encode bound")
     out = np.empty(cap.value, dtype=np.uint8)
     w = ctypes.c_uint64(0)
+    t0 = time.perf_counter()
     native.check(L.snappy_lz4net_encode(payload.ctypes.data, payload.size, 1 << 20, out.ctypes.data, out.size,
                                         ctypes.byref(w)), "snappy_lz4net_encode")
+    _ARCHIVES_WRITTEN["call_s"] += time.perf_counter() - t0
+    _ARCHIVES_WRITTEN["bytes"] += int(payload.size)
+    _ARCHIVES_WRITTEN["kernel_ms"] += max(0.0, float(L.snappy_profile_last_ms(1)))
     return out[: w.value].copy(), int(payload.size), payload
+
+
+# The write side, measured where the bench makes its input archives (not part of any timed step).
+_ARCHIVES_WRITTEN = {"bytes": 0, "call_s": 0.0, "kernel_ms": 0.0}
+
+
+def archives_written_summary():
+    a = _ARCHIVES_WRITTEN
+    if not a["bytes"] or a["kernel_ms"] <= 0.0:
+        return None
+    return {"what": "snappy_lz4net_encode over the archives this workload imports (payload in host memory -> "
+                    "lz4net stream in host memory, 1 MiB chunks), one call per archive, outside the timed steps",
+            "decoded_bytes": a["bytes"], "kernel_ms": a["kernel_ms"],
+            "kernel_GBps_in": a["bytes"] / a["kernel_ms"] / 1e6,
+            "call_GBps_in": a["bytes"] / a["call_s"] / 1e9}
 
 
 def run_mcdf(args, rank, world, local_rank, dist):
@@ -251,6 +270,7 @@ def run_mcdf(args, rank, world, local_rank, dist):
     lib.snappy_profile_enable(1)
     rng = np.random.default_rng(0x4D434446 + rank)
     n_arch = max(1, int(args.archives))
+    _ARCHIVES_WRITTEN.update(bytes=0, call_s=0.0, kernel_ms=0.0)
     content = getattr(args, "mcdf_content", "asset")
     spec = getattr(args, "mcdf_shape", "uniform") == "spec"
     streams, sizes, first_payload = [], [], None
@@ -283,6 +303,7 @@ def run_mcdf(args, rank, world, local_rank, dist):
             files_per_archive.append(100)
             if a == 0:
                 first_payload = payload
+    written = archives_written_summary()
     comp_bytes = int(sum(s.size for s in streams))
     out_bytes = int(sum(sizes))
     ptrs = (ctypes.c_void_p * n_arch)(*[s.ctypes.data for s in streams])
@@ -385,6 +406,7 @@ def run_mcdf(args, rank, world, local_rank, dist):
                      # the practical ceiling next to the 8 TB/s of the data sheet.
                      "device_copy_GBps_measured": device_copy_rate(torch, min(out_bytes, 2 << 30))},
         "digests_match_hashlib_sample": bool(ok),
+        **({"archives_written": written} if written else {}),
         **({"cpu_baseline": cpu} if cpu else {}),
     }
 
@@ -666,6 +688,8 @@ def extra_workloads(args, lib, native, torch, device, local_rank, n_cu):
                     "compressed_bytes": m["config"]["compressed_bytes_per_gpu"],
                     "decoded_bytes": m["config"]["decoded_bytes_per_gpu"],
                     "digests_match_hashlib_sample": m["digests_match_hashlib_sample"]}
+        if m.get("archives_written"):
+            res[key]["archives_written"] = m["archives_written"]
         if "cpu_baseline" in m:
             res[key]["cpu_baseline"] = m["cpu_baseline"]
     return res
