@@ -38,7 +38,7 @@ constexpr uint32_t kMinMatch = 4;
 constexpr uint32_t kMfLimit = 12;      // no match may start in the last 12 bytes
 constexpr uint32_t kLastLiterals = 5;  // the last 5 bytes are always literals
 #ifndef SNAPPY_LZ4_ENC_WINDOWS
-#define SNAPPY_LZ4_ENC_WINDOWS 4
+#define SNAPPY_LZ4_ENC_WINDOWS 8
 #endif
 constexpr uint32_t kWindows = SNAPPY_LZ4_ENC_WINDOWS;  // windows of 64 positions per memory round trip
 
