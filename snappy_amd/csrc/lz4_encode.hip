@@ -72,8 +72,14 @@ __device__ __forceinline__ uint32_t put_literals(uint8_t *__restrict__ out, uint
     ++o;
     if (lit >= 15)
         o = put_length(out, o, lit - 15, lane);
-    // Dwords at any byte address, the last lit & 3 bytes one per lane; every load of a pass is
-    // issued before its first store (a load behind a store would wait for a trip of its own).
+    if (lit <= 64u) {  // a short run is one byte per lane: a single load and store, nothing to piece together
+        if (lane < lit)
+            out[o + lane] = src[lane];
+        return o + lit;
+    }
+    // Longer runs in dwords at any byte address, the last lit & 3 bytes one per lane; every load
+    // of a pass is issued before its first store (a load behind a store would wait for a trip of
+    // its own).
     const uint32_t whole = lit & ~3u;
     const bool tail = lane < (lit & 3u);
     const uint8_t last = tail ? src[whole + lane] : uint8_t(0);
