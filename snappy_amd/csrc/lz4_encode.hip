@@ -12,7 +12,7 @@
 // Greedy matching, 64 positions at a time: lane i hashes the 4 bytes at
 // position ip + i, looks its candidate up in an LDS table of 8192 earlier
 // positions and enters its own position; the first lane with a verified match
-// wins, the wave extends the match (64 bytes, then 256 per step), emits "literals so far +
+// wins, the wave extends the match (64 bytes, then up to 1 KiB per step), emits "literals so far +
 // match" cooperatively and continues behind it.  Without a match the window
 // moves on by 64.
 //
@@ -83,13 +83,19 @@ __device__ __forceinline__ uint32_t put_literals(uint8_t *__restrict__ out, uint
     const uint32_t whole = lit & ~3u;
     const bool tail = lane < (lit & 3u);
     const uint8_t last = tail ? src[whole + lane] : uint8_t(0);
-    {
-        const uint32_t i = 4u * lane;
-        const uint32_t v = i < whole ? load32(src + i) : 0u;
-        if (i < whole)
-            store32(out + o + i, v);
+    // Passes of 4 KiB (16 bytes per lane, four of them in flight) while that much is left, ...
+    uint32_t done = 0;
+    for (; done + 4096u <= whole; done += 4096u) {
+        uint4 v[4];
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k)
+            __builtin_memcpy(&v[k], src + done + 16u * lane + 1024u * k, 16);
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k)
+            __builtin_memcpy(out + o + done + 16u * lane + 1024u * k, &v[k], 16);
     }
-    for (uint32_t i = 256u + 4u * lane; i < whole; i += 1024u) {
+    // ... then of 1 KiB, a dword per lane.
+    for (uint32_t i = done + 4u * lane; i < whole; i += 1024u) {
         uint32_t v[4];
 #pragma unroll
         for (uint32_t k = 0; k < 4u; ++k)
@@ -223,7 +229,7 @@ lz4_encode_kernel(const uint8_t *__restrict__ base_in, uint8_t *__restrict__ bas
             const uint32_t m = ip + 64u * w + first;
             const uint32_t ref = __builtin_amdgcn_readlane(ref_all, first);
             // The first 64 bytes one per lane (most matches end there, and a byte load has nothing
-            // to take apart), then four bytes per lane and step; a lane's dword may reach past
+            // to take apart), then 16 or 4 bytes per lane and step; a lane's dword may reach past
             // matchlimit (never past the chunk's end: matchlimit is 5 bytes short of it), its
             // bytes beyond do not count.
             uint32_t mlen = kMinMatch;
@@ -235,6 +241,27 @@ lz4_encode_kernel(const uint8_t *__restrict__ base_in, uint8_t *__restrict__ bas
                 open_end = differ == 0;
                 mlen += open_end ? 64u : static_cast<uint32_t>(__builtin_ctzll(differ));
             }
+            // (1 KiB per step, 16 bytes per lane, while that much may still be covered, ...)
+            while (open_end && m + mlen + 1024u <= matchlimit) {
+                uint4 a, b;
+                __builtin_memcpy(&a, in + m + mlen + 16u * lane, 16);
+                __builtin_memcpy(&b, in + ref + mlen + 16u * lane, 16);
+                const uint32_t x[4] = {a.x ^ b.x, a.y ^ b.y, a.z ^ b.z, a.w ^ b.w};
+                uint32_t same = 16u;
+#pragma unroll
+                for (uint32_t k = 4; k-- > 0;)
+                    if (x[k] != 0u)
+                        same = 4u * k + (static_cast<uint32_t>(__builtin_ctz(x[k])) >> 3);
+                const uint64_t differ = __ballot(same < 16u);
+                if (differ) {
+                    const uint32_t at = static_cast<uint32_t>(__builtin_ctzll(differ));
+                    mlen += 16u * at + __builtin_amdgcn_readlane(same, at);
+                    open_end = false;
+                    break;
+                }
+                mlen += 1024u;
+            }
+            // (... then a dword per lane.)
             while (open_end) {
                 const uint32_t q = m + mlen + 4u * lane;
                 const uint32_t valid = q + 4u <= matchlimit ? 4u : (q < matchlimit ? matchlimit - q : 0u);
